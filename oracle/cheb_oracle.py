@@ -1,0 +1,251 @@
+"""CPU oracle for the Mesh-VAE ChebConv-VAE hot path.  TEST INFRASTRUCTURE ONLY.
+
+A plain-PyTorch (CPU, fp32, autograd) restatement of the reference algorithm,
+written from the reference's maths and dataflow -- *not* a copy of its files.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it; the product path (``mesh-vae_amd/``) never does and raises if
+its HIP library is missing.
+
+Parity pin: every function here is checked (tests/test_oracle_golden.py) against
+golden vectors captured by running the reference's own Python in the build
+container (oracle/make_golden.py -> tests/golden/*.npz).  The reference has no
+tests or fixtures of its own and its third-party arithmetic
+(torch-scatter 2.0.9 ``scatter(reduce='add')``, torch-geometric 2.0.4
+``remove_self_loops``) is absent from the image; those two are restated from their
+published semantics in oracle/refshim (sum-scatter, row!=col mask).
+
+Reference anchors (file:line under /root/reference):
+  nn/conv.py:541-555   ChebConv_batch.norm            -> cheb_norm
+  nn/conv.py:171-229,242-331,346-364,579-581          -> propagate
+  nn/conv.py:557-577   ChebConv_batch.forward         -> cheb_conv
+  nn/pool.py:13-23     SurfacePool                    -> surface_pool
+  models/cheb_VAE.py:104-351 cheb_VAE                 -> OracleVAE
+  logpdf.py:7-8,22-28  KLD / gaussian_nll / softclip  -> kld / gaussian_nll / softclip
+  model.py:24-32       COO construction               -> coo_from_arrays
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- row N
+def cheb_norm(edge_index, num_nodes, edge_weight=None, dtype=None):
+    """nn/conv.py:541-555.  Drop self loops; unit weights; deg = sum of weights per
+    edge_index[0]; norm[e] = -deg^-1/2[row] * w * deg^-1/2[col] with inf -> 0."""
+    keep = edge_index[0] != edge_index[1]
+    edge_index = edge_index[:, keep]
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=edge_index.device)
+    else:
+        edge_weight = edge_weight[keep]
+    row, col = edge_index[0], edge_index[1]
+    deg = torch.zeros(num_nodes, dtype=edge_weight.dtype).scatter_add_(0, row, edge_weight)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    return edge_index, -dis[row] * edge_weight * dis[col]
+
+
+# --------------------------------------------------------------------------- row P
+def propagate(x, gather_idx, scatter_idx, weight, n_out):
+    """nn/conv.py:199-200 (index_select), :579-581 (message = w * x_j), :363 (sum-scatter).
+    x is [N_in, B, C] (the reference's transposed view); returns [n_out, B, C].
+    The message tensor [E, B, C] is materialised exactly as the reference does."""
+    msg = weight.view(-1, 1, 1) * x.index_select(0, gather_idx)
+    out = torch.zeros((n_out,) + tuple(x.shape[1:]), dtype=msg.dtype)
+    return out.scatter_add_(0, scatter_idx.view(-1, 1, 1).expand_as(msg), msg)
+
+
+# --------------------------------------------------------------------------- row C (+Q)
+def cheb_conv(x, edge_index, norm, weight, bias=None):
+    """nn/conv.py:557-577.  x [B,N,Cin]; weight [K,Cin,Cout].  flow source_to_target:
+    messages are gathered at edge_index[0] and summed at edge_index[1] (nn/conv.py:172).
+    dim_size is x.size(node_dim) (nn/conv.py:225-227 with size=None), so an edge list
+    smaller than N (the final-layer quirk, cheb_VAE.py:288) leaves rows >= max index zero."""
+    n = x.size(1)
+    out = torch.matmul(x, weight[0])
+    xt = x.transpose(0, 1)
+    t0 = xt
+    if weight.size(0) > 1:
+        t1 = propagate(xt, edge_index[0], edge_index[1], norm, n)
+        out = out + torch.matmul(t1.transpose(0, 1), weight[1])
+    for k in range(2, weight.size(0)):
+        t2 = 2 * propagate(t1, edge_index[0], edge_index[1], norm, n) - t0
+        out = out + torch.matmul(t2.transpose(0, 1), weight[k])
+        t0, t1 = t1, t2
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+# --------------------------------------------------------------------------- row S
+def surface_pool(x, indices, values, size):
+    """nn/pool.py:17-20.  flow target_to_source: gather at indices[1] (matrix column),
+    sum at indices[0] (matrix row); size = pool_mat.size() = (N_out, N_in)."""
+    if x.size(1) != size[1]:
+        raise ValueError(f"Encountered node tensor with size {x.size(1)} in dimension 0, "
+                         f"but expected size {size[1]}.")
+    return propagate(x.transpose(0, 1), indices[1], indices[0], values, size[0]).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------- logpdf.py
+def kld(mu, logvar):
+    """logpdf.py:7-8."""
+    return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), -1)
+
+
+def softclip(t, lo):
+    """logpdf.py:24-28."""
+    return lo + F.softplus(t - lo)
+
+
+def gaussian_nll(mu, log_sigma, x):
+    """logpdf.py:22-23."""
+    return 0.5 * torch.pow((x - mu) / log_sigma.exp(), 2) + log_sigma + 0.5 * np.log(2 * np.pi)
+
+
+# --------------------------------------------------------------------------- model.py:24-32
+def coo_from_arrays(row, col, val, shape):
+    idx = torch.from_numpy(np.vstack([row, col]).astype(np.int64))
+    return idx, torch.from_numpy(np.asarray(val, dtype=np.float32)), tuple(int(s) for s in shape)
+
+
+class Topology:
+    """The A/D/U lists exactly as cheb_VAE.__init__ receives them (cheb_VAE.py:114-119),
+    loaded from a tests/golden/topology_*.npz fixture."""
+
+    def __init__(self, npz):
+        self.num_nodes = [int(v) for v in npz["num_nodes"]]
+        n = len(self.num_nodes)
+        self.A = [coo_from_arrays(npz[f"A{i}_row"], npz[f"A{i}_col"], npz[f"A{i}_val"],
+                                  (self.num_nodes[i],) * 2) for i in range(n)]
+        self.D = [coo_from_arrays(npz[f"D{i}_row"], npz[f"D{i}_col"], npz[f"D{i}_val"],
+                                  npz[f"D{i}_shape"]) for i in range(n - 1)]
+        self.U = [coo_from_arrays(npz[f"U{i}_row"], npz[f"U{i}_col"], npz[f"U{i}_val"],
+                                  npz[f"U{i}_shape"]) for i in range(n - 1)]
+
+    def sparse(self, which, device="cpu"):
+        return [torch.sparse_coo_tensor(i, v, s, check_invariants=False).to(device)
+                for (i, v, s) in getattr(self, which)]
+
+
+# --------------------------------------------------------------------------- rows E K Z R D L F I
+def init_state_dict(config, topo, num_features=3):
+    """Row I (cheb_VAE.py:106-172, 349-351): parameters drawn in module-creation order
+    from the *current* default torch generator: cheb[i] (W then b, N(0,.1)); cheb_dec[i]
+    (W then b; the last bias is drawn then dropped, :135); classifier_layer, z_mean,
+    z_log_var, enc_lin, dec_lin, dec_lin_1, dec_lin_2 (nn.Linear defaults); finally
+    enc_lin.weight and dec_lin.weight redrawn N(0,.1)."""
+    filters = [num_features] + list(config["num_conv_filters"])
+    K = config["polygon_order"]
+    sd = {}
+
+    def conv(prefix, cin, cout, k, keep_bias=True):
+        w = torch.empty(k, cin, cout).normal_(0, 0.1)
+        b = torch.empty(cout).normal_(0, 0.1)
+        sd[prefix + ".weight"] = w
+        if keep_bias:
+            sd[prefix + ".bias"] = b
+
+    for i in range(len(filters) - 2):
+        conv(f"cheb.{i}", filters[i], filters[i + 1], K[i])
+    nd = len(filters) - 1
+    for i in range(nd):
+        conv(f"cheb_dec.{i}", filters[-i - 1], filters[-i - 2], K[i], keep_bias=(i != nd - 1))
+
+    def linear(prefix, fin, fout):
+        lin = torch.nn.Linear(fin, fout)
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = lin.weight.detach(), lin.bias.detach()
+
+    nh, nc, nz = config["num_hidden"], config["num_classes"], config["num_style"]
+    flat = topo.D[-1][2][0] * filters[-1]
+    linear("classifier_layer", nh, nc)
+    linear("z_mean", nh + nc, nz)
+    linear("z_log_var", nh + nc, nz)
+    linear("enc_lin", flat, nh)
+    linear("dec_lin", nz + nc, nh)
+    linear("dec_lin_1", nz + nc, nh)
+    linear("dec_lin_2", nh, flat)
+    sd["enc_lin.weight"] = torch.empty(nh, flat).normal_(0, 0.1)
+    sd["dec_lin.weight"] = torch.empty(nh, nz + nc).normal_(0, 0.1)
+    return sd
+
+
+class OracleVAE:
+    """Functional restatement of cheb_VAE (models/cheb_VAE.py:104-351) over a state_dict."""
+
+    def __init__(self, config, topo, state_dict, num_features=3, requires_grad=False):
+        self.n_layers = config["n_layers"]
+        self.filters = [num_features] + list(config["num_conv_filters"])
+        self.p_drop = float(config["dropout"])
+        self.topo = topo
+        self.edge, self.norm = zip(*[cheb_norm(topo.A[i][0], topo.num_nodes[i])
+                                     for i in range(len(topo.num_nodes))])   # cheb_VAE.py:118-119
+        self.p = {k: v.detach().clone().float().requires_grad_(requires_grad) for k, v in state_dict.items()}
+        self.training = False
+
+    def _drop(self, x):
+        return F.dropout(x, self.p_drop, self.training)
+
+    def _conv(self, name, x, level):
+        return cheb_conv(x, self.edge[level], self.norm[level], self.p[name + ".weight"],
+                         self.p.get(name + ".bias"))
+
+    def encoder(self, x):                                    # cheb_VAE.py:261-273
+        for i in range(self.n_layers):
+            x = F.relu(self._conv(f"cheb.{i}", x, i))
+            x = surface_pool(x, *self.topo.D[i])
+        x = x.reshape(x.shape[0], -1)
+        x = F.relu(F.linear(x, self.p["enc_lin.weight"], self.p["enc_lin.bias"]))
+        return self._drop(x)
+
+    def classifier(self, h):                                 # cheb_VAE.py:253-258
+        h = self._drop(h)
+        return F.softmax(F.linear(h, self.p["classifier_layer.weight"], self.p["classifier_layer.bias"]), dim=1)
+
+    def decoder(self, z):                                    # cheb_VAE.py:275-292
+        x = self._drop(F.relu(F.linear(z, self.p["dec_lin.weight"], self.p["dec_lin.bias"])))
+        x = self._drop(F.relu(F.linear(x, self.p["dec_lin_2.weight"], self.p["dec_lin_2.bias"])))
+        x = x.reshape(x.shape[0], -1, self.filters[-1])
+        for i in range(self.n_layers):
+            x = surface_pool(x, *self.topo.U[-i - 1])
+            x = F.relu(self._conv(f"cheb_dec.{i}", x, self.n_layers - i - 1))
+        # the quirk (cheb_VAE.py:288): coarsest-level edges on the finest tensor
+        return self._conv(f"cheb_dec.{self.n_layers}", x, len(self.edge) - 1)
+
+    def sample(self, y, z):                                  # cheb_VAE.py:294-305
+        return self.decoder(torch.cat([y, z], -1)).reshape(z.shape[0], -1, self.filters[0])
+
+    def loss_function(self, x, recon, mu, logvar, y, y_hat):  # cheb_VAE.py:321-346
+        k = kld(mu, logvar)
+        log_sigma = softclip(torch.Tensor([1]), -6)
+        rec = gaussian_nll(recon, log_sigma, x).sum(-1).sum(-1)
+        correct = torch.sum(torch.argmax(y_hat, dim=1) == torch.argmax(y, dim=1))
+        logqy = (y_hat * y).sum(-1).log()
+        return (k + rec - 2 * logqy).mean(), correct, k, rec
+
+    def forward(self, x, x_gt, y, m_type="test", eps=None):   # cheb_VAE.py:190-251
+        B = x.shape[0]
+        h = self.encoder(x.reshape(B, -1, self.filters[0]))
+        y_hat = self.classifier(h)
+        hy = torch.cat([y, h], -1)
+        mu = F.linear(hy, self.p["z_mean.weight"], self.p["z_mean.bias"])
+        logvar = F.linear(hy, self.p["z_log_var.weight"], self.p["z_log_var.bias"])
+        if m_type == "train":                                # cheb_VAE.py:309-319
+            if eps is None:
+                eps = torch.normal(mean=0, std=1, size=tuple(mu.shape))
+            z_ = eps * torch.exp(logvar * 0.5) + mu
+        else:
+            z_ = mu
+        recon = self.decoder(torch.cat([y, z_], -1)).reshape(B, -1, self.filters[0])
+        loss, correct, k, rec = self.loss_function(x_gt, recon, mu, logvar, y, y_hat)
+        return loss, correct, recon, [k, rec, z_], y_hat, mu, logvar
+
+    def grads(self):
+        return {k: v.grad for k, v in self.p.items() if v.grad is not None}
+
+
+def log_sigma_const():
+    """-6 + softplus(1 + 6) (cheb_VAE.py:329-330)."""
+    return -6.0 + math.log1p(math.exp(7.0))

@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mesh-vae_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def topo5k_npz():
+    return load_golden("topology_5k.npz")
+
+
+@pytest.fixture(scope="session")
+def topotiny_npz():
+    return load_golden("topology_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def ops_npz():
+    return load_golden("ops_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def model_tiny_npz():
+    return load_golden("model_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def model_5k_npz():
+    return load_golden("model_5k.npz")
+
+
+TINY_CFG = {"n_layers": 2, "num_conv_filters": [8, 16, 16], "polygon_order": [6, 6, 6],
+            "num_classes": 2, "num_style": 16, "num_hidden": 64, "dropout": 0.2}
+CFG_5K = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_order": [6, 6, 6, 6, 6],
+          "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
+
+
+def state_dict_from(npz):
+    import torch
+    return {str(k): torch.from_numpy(npz[f"sd/{k}"]) for k in npz["sd_keys"]}

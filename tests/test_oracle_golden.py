@@ -1,0 +1,143 @@
+"""CPU: pin the oracle (oracle/cheb_oracle.py) against vectors captured from the reference
+itself (oracle/make_golden.py).  Tolerances: the oracle restates the same op sequence, so
+agreement is at fp32 rounding level (1e-6 relative)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFG_5K, TINY_CFG, state_dict_from
+from oracle import cheb_oracle as O
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_topology_hashes_match_survey_probe(topo5k_npz):
+    # SURVEY.md section 8(c) probe hashes of the reference-generated hierarchy
+    want = ["392d175745f568af", "e69d8c2b28c39335", "b9e6a3ede1512b5f", "2e8b03dcdc4feec8", "ea634efafdf9a9c6"]
+    for i, w in enumerate(want):
+        a = np.vstack([topo5k_npz[f"A{i}_row"], topo5k_npz[f"A{i}_col"]]).astype(np.int64)
+        assert _sha16(a) == w
+    assert list(topo5k_npz["num_nodes"]) == [4998, 1250, 313, 79, 20]
+    assert _sha16(topo5k_npz["D0_col"].astype(np.int64)) == "613c3bdbdee65086"
+    for i in range(4):
+        assert np.all(topo5k_npz[f"D{i}_val"] == 1.0)
+        assert len(topo5k_npz[f"U{i}_row"]) == 3 * topo5k_npz["num_nodes"][i]
+
+
+@pytest.mark.parametrize("which", ["5k", "tiny"])
+def test_cheb_norm(which, topo5k_npz, topotiny_npz):
+    npz = topo5k_npz if which == "5k" else topotiny_npz
+    for i in range(int(npz["n_levels"])):
+        ei = _t(np.vstack([npz[f"A{i}_row"], npz[f"A{i}_col"]]).astype(np.int64))
+        ei2, nrm = O.cheb_norm(ei, int(npz["num_nodes"][i]))
+        assert torch.equal(ei2, ei)
+        assert torch.equal(nrm, _t(npz[f"A{i}_norm"]))
+    if which == "5k":
+        assert abs(float(topo5k_npz["A0_norm"][0]) + 1 / np.sqrt(42)) < 1e-7
+
+
+def test_cheb_conv_cases(ops_npz, topotiny_npz):
+    for case in ops_npz["case_names"]:
+        level, n_x, B, cin, cout, K, has_b = [int(v) for v in ops_npz[f"{case}_meta"]]
+        ei = _t(np.vstack([topotiny_npz[f"A{level}_row"], topotiny_npz[f"A{level}_col"]]).astype(np.int64))
+        ei, nrm = O.cheb_norm(ei, int(topotiny_npz["num_nodes"][level]))
+        x = _t(ops_npz[f"{case}_x"]).requires_grad_(True)
+        w = _t(ops_npz[f"{case}_w"]).requires_grad_(True)
+        b = _t(ops_npz[f"{case}_b"]).requires_grad_(True) if has_b else None
+        y = O.cheb_conv(x, ei, nrm, w, b)
+        torch.testing.assert_close(y, _t(ops_npz[f"{case}_y"]), rtol=1e-6, atol=1e-6)
+        y.backward(_t(ops_npz[f"{case}_gy"]))
+        torch.testing.assert_close(x.grad, _t(ops_npz[f"{case}_gx"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(w.grad, _t(ops_npz[f"{case}_gw"]), rtol=1e-5, atol=1e-5)
+        if has_b:
+            torch.testing.assert_close(b.grad, _t(ops_npz[f"{case}_gb"]), rtol=1e-5, atol=1e-5)
+
+
+def test_quirk_closed_form(ops_npz):
+    """cheb_VAE.py:288: rows >= 11 (coarsest level size) see Tx1=0, Tx2=-x, Tx3=0, Tx4=x, Tx5=0."""
+    x, w, y = (_t(ops_npz[f"c_quirk_16_3_k6_{k}"]) for k in ("x", "w", "y"))
+    closed = x[:, 11:] @ (w[0] - w[2] + w[4])
+    torch.testing.assert_close(y[:, 11:], closed, rtol=1e-5, atol=1e-5)
+
+
+def test_surface_pool_cases(ops_npz, topotiny_npz):
+    topo = O.Topology(topotiny_npz)
+    for tag, mat in (("p_D0", topo.D[0]), ("p_D1", topo.D[1]), ("p_U0", topo.U[0]), ("p_U1", topo.U[1])):
+        x = _t(ops_npz[f"{tag}_x"]).requires_grad_(True)
+        y = O.surface_pool(x, *mat)
+        assert torch.equal(y, _t(ops_npz[f"{tag}_y"]))          # same op sequence -> bit-exact
+        y.backward(_t(ops_npz[f"{tag}_gy"]))
+        torch.testing.assert_close(x.grad, _t(ops_npz[f"{tag}_gx"]), rtol=1e-6, atol=1e-6)
+    # D is a pure row gather
+    x = _t(ops_npz["p_D0_x"])
+    assert torch.equal(_t(ops_npz["p_D0_y"]), x[:, topo.D[0][0][1]])
+    with pytest.raises(ValueError):
+        O.surface_pool(x[:, :-1], *topo.D[0])
+
+
+def test_logpdf(ops_npz):
+    assert torch.equal(O.kld(_t(ops_npz["kld_mu"]), _t(ops_npz["kld_lv"])), _t(ops_npz["kld_out"]))
+    ls = O.softclip(torch.Tensor([1]), -6)
+    assert torch.equal(ls, _t(ops_npz["log_sigma"]))
+    assert abs(O.log_sigma_const() - float(ls)) < 1e-6
+    assert torch.equal(O.gaussian_nll(_t(ops_npz["nll_mu"]), ls, _t(ops_npz["nll_x"])), _t(ops_npz["nll_out"]))
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_init_order_matches_reference(which, model_tiny_npz, model_5k_npz, topotiny_npz, topo5k_npz):
+    npz, tnpz, cfg = (model_tiny_npz, topotiny_npz, TINY_CFG) if which == "tiny" else (model_5k_npz, topo5k_npz, CFG_5K)
+    torch.manual_seed(666)
+    sd = O.init_state_dict(cfg, O.Topology(tnpz))
+    want = state_dict_from(npz)
+    assert list(sd.keys()) != [] and set(sd.keys()) == set(want.keys())
+    for k in want:
+        assert torch.equal(sd[k], want[k]), k
+    if which == "5k":
+        assert len(want) == 31 and sum(v.numel() for v in want.values()) == 712642
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_full_model_eval_and_train(which, model_tiny_npz, model_5k_npz, topotiny_npz, topo5k_npz):
+    npz, tnpz, cfg = (model_tiny_npz, topotiny_npz, TINY_CFG) if which == "tiny" else (model_5k_npz, topo5k_npz, CFG_5K)
+    topo = O.Topology(tnpz)
+    sd = state_dict_from(npz)
+    x, y = _t(npz["x"]), _t(npz["y"])
+    net = O.OracleVAE(cfg, topo, sd)
+    with torch.no_grad():
+        loss, correct, recon, (k, rec, z_), y_hat, mu, logvar = net.forward(x, x.clone(), y, "test")
+        loss64, _, _, (_, rec64, _), _, _, _ = net.forward(x, x.double(), y, "test")
+        oppo = net.sample(1 - y, z_)
+    tol = dict(rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(y_hat, _t(npz["eval/y_hat"]), **tol)
+    torch.testing.assert_close(mu, _t(npz["eval/mu"]), **tol)
+    torch.testing.assert_close(logvar, _t(npz["eval/logvar"]), **tol)
+    torch.testing.assert_close(k, _t(npz["eval/kld"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(recon, _t(npz["eval/recon"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(oppo, _t(npz["eval/oppo_recon"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rec, _t(npz["eval/rec"]), rtol=1e-6, atol=1e-2)
+    torch.testing.assert_close(loss, _t(npz["eval/loss"]), rtol=1e-6, atol=1e-2)
+    assert rec64.dtype == torch.float64 and loss64.dtype == torch.float64   # SURVEY section 7 "fp64 loss"
+    torch.testing.assert_close(rec64, _t(npz["eval/rec64"]), rtol=1e-9, atol=1e-4)
+    assert int(correct) == int(npz["eval/correct"])
+
+    cfg0 = dict(cfg, dropout=0.0)
+    net = O.OracleVAE(cfg0, topo, sd, requires_grad=True)
+    net.training = True
+    torch.manual_seed(123)
+    loss, correct, recon, (k, rec, z_), y_hat, mu, logvar = net.forward(x, x.clone(), y, "train")
+    loss.backward()
+    torch.testing.assert_close(z_, _t(npz["train/z"]), **tol)
+    torch.testing.assert_close(loss, _t(npz["train/loss"]), rtol=1e-6, atol=1e-2)
+    g = net.grads()
+    assert set(g.keys()) == set(str(n) for n in npz["train/grad_names"])
+    assert "dec_lin_1.weight" not in g                         # never used (cheb_VAE.py:165)
+    for name, grad in g.items():
+        torch.testing.assert_close(grad, _t(npz[f"train/grad/{name}"]), rtol=1e-4, atol=1e-5, msg=name)
