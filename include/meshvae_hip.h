@@ -1,0 +1,154 @@
+/* meshvae_hip.h -- C ABI of libmeshvae_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the Mesh-VAE ChebConv-VAE hot path.  Every entry point
+ * takes plain device pointers + sizes + a HIP stream (no torch types) and replaces
+ * the arithmetic of one reference interface, cited per function as file:line under
+ * the reference tree.  The reference is pure Python on torch/torch_scatter, so the
+ * "FFI" a maintainer adds is a ctypes stub; the host-side mirror
+ * of the reference's own classes lives in mesh-vae_amd/{nn,models,model.py,logpdf.py}.
+ *
+ * Conventions
+ *   - all tensors are dense, contiguous, row-major fp32 unless stated; activations
+ *     are [B, N, C] (batch, vertex, channel) exactly as the reference's modules
+ *     receive them (nn/conv.py:557, nn/pool.py:17);
+ *   - sparse operators are CSR over OUTPUT rows with int32 indices; the order of a
+ *     row's entries is the order of the reference's COO edge list, so sums run in
+ *     the reference's accumulation order;
+ *   - `stream` is a hipStream_t (0 = default stream); all work is asynchronous on it;
+ *   - return value 0 = success, anything else = failure with a message available
+ *     from mvh_last_error() (thread-local).  Nothing here allocates device memory:
+ *     workspaces are caller-provided and sized by the *_ws_bytes queries, so every
+ *     call is hipGraph-capturable.
+ */
+#ifndef MESHVAE_HIP_H
+#define MESHVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvh_stream_t;
+
+#define MVH_OK 0
+#define MVH_ERR_INVALID 1
+#define MVH_ERR_HIP 2
+#define MVH_ERR_UNSUPPORTED 3
+
+#define MVH_ACT_NONE 0
+#define MVH_ACT_RELU 1
+
+/* CSR operator over output rows: y[r] = sum_{e in [rowptr[r], rowptr[r+1])} val[e] * x[col[e]]. */
+typedef struct mvh_csr {
+  int32_t n_rows;        /* output rows  */
+  int32_t n_cols;        /* input rows   */
+  int32_t nnz;
+  const int32_t* rowptr; /* [n_rows+1] device */
+  const int32_t* col;    /* [nnz]      device */
+  const float* val;      /* [nnz]      device */
+} mvh_csr_t;
+
+int mvh_version(void);
+const char* mvh_last_error(void);
+/* Device properties of the current HIP device (arch string e.g. "gfx950"). */
+int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- row P: MessagePassing.propagate (nn/conv.py:242-331 with __collect__ :171-229,
+ * message :579-581, aggregate :346-364).  y[b,r,:] = add[b,r,:] + alpha * sum_e val[e] *
+ * x[b,col[e],:] + beta * z[b,r,:].  add / z may be NULL.  exact != 0 rounds every product
+ * and every add separately in edge order (bit-identical to the reference's fp32
+ * index_select -> mul -> scatter_add_); exact == 0 allows FMA contraction. */
+int mvh_spmm(mvh_stream_t stream, const mvh_csr_t* op, const float* x, float* y,
+             const float* add, const float* z, float alpha, float beta,
+             int32_t B, int32_t C, int32_t exact);
+
+/* ---- row S: SurfacePool.forward (nn/pool.py:17-20): y[B,n_rows,C] = P x[B,n_cols,C],
+ * bit-exact (D: pure row gather; U: 3 taps in COO order). */
+int mvh_pool_fwd(mvh_stream_t stream, const mvh_csr_t* pool, const float* x, float* y,
+                 int32_t B, int32_t C);
+/* Backward of row S (autograd of index_select/mul/scatter_add in the reference):
+ * dx[B,n_cols,C] = P^T dy; `pool_t` is the CSR of P^T (rows = n_cols of P). */
+int mvh_pool_bwd(mvh_stream_t stream, const mvh_csr_t* pool_t, const float* dy, float* dx,
+                 int32_t B, int32_t C);
+
+/* ---- rows C + Q: ChebConv_batch.forward (nn/conv.py:557-577) (+ F.relu, cheb_VAE.py:264,285).
+ * out[B,N,Cout] = act( sum_k T_k(L) x W[k] + bias ), T_0 = x, T_1 = L x,
+ * T_k = 2 L T_{k-1} - T_{k-2}.  `lap` is the CSR (by target vertex) of the edge list
+ * with the norm of nn/conv.py:541-555 as values; lap->n_rows == lap->n_cols == N, and
+ * rows without edges are simply empty (the final-layer quirk, cheb_VAE.py:288).
+ * W is [K,Cin,Cout]; bias [Cout] or NULL.  `ws` must hold mvh_cheb_conv_ws_bytes().
+ * If `tx_saved` is non-NULL it receives T_1..T_{K-1} ([K-1,B,N,Cin]) for the backward. */
+size_t mvh_cheb_conv_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K);
+int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
+                      const float* bias, float* out, float* tx_saved,
+                      int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                      void* ws, size_t ws_bytes);
+/* Backward of rows C + Q (the reference relies on autograd; analytic form: SURVEY 7.6).
+ * dout is the gradient w.r.t. the activated output; `out` is the forward output (used as
+ * the ReLU mask when act == MVH_ACT_RELU, may be NULL otherwise).  `lap_t` is the CSR of
+ * L^T (== lap for the symmetric mesh Laplacian).  tx_saved may be NULL (T_k recomputed).
+ * dx may be NULL (first layer).  dW [K,Cin,Cout] and db [Cout] (NULL if no bias) are
+ * overwritten (not accumulated). */
+size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K);
+int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
+                      const float* x, const float* W, const float* out, const float* dout,
+                      const float* tx_saved, float* dx, float* dW, float* db,
+                      int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                      void* ws, size_t ws_bytes);
+
+/* ---- rows E/D (dense parts): nn.Linear + F.relu + nn.Dropout (cheb_VAE.py:270-272,277-280).
+ * y[B,out] = drop( act( x[B,in] W[out,in]^T + bias ) ); drop keeps element i when
+ * drop_u[i] >= p and scales by 1/(1-p); drop_u == NULL or p == 0 disables it. */
+int mvh_linear_fwd(mvh_stream_t stream, const float* x, const float* W, const float* bias,
+                   float* y, int32_t B, int32_t in_f, int32_t out_f, int32_t act,
+                   const float* drop_u, float p);
+/* dx may be NULL.  `y` is the forward output (mask for relu/dropout).  ws: B*out_f floats. */
+int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* W, const float* y,
+                   const float* dy, float* dx, float* dW, float* db,
+                   int32_t B, int32_t in_f, int32_t out_f, int32_t act, float p,
+                   void* ws, size_t ws_bytes);
+
+/* ---- rows K + Z + R: classifier (cheb_VAE.py:253-258), latent heads (:209-226) and
+ * reparameterize (:309-319).  h [B,H] (encoder output), y [B,C] one-hot as float,
+ * drop_u [B,H] uniforms for the classifier's second dropout (NULL = eval), eps [B,Z]
+ * host-drawn N(0,1) (NULL => z = mu, the m_type="test" path).
+ * Outputs: y_hat [B,C] softmax, mu/logvar/z [B,Z], zy [B,C+Z] = cat[y, z]. */
+int mvh_vae_latent_fwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
+                       float p, const float* Wc, const float* bc, const float* Wm, const float* bm,
+                       const float* Wv, const float* bv, const float* eps,
+                       float* y_hat, float* mu, float* logvar, float* z, float* zy,
+                       int32_t B, int32_t H, int32_t C, int32_t Z);
+/* Backward: incoming d_yhat [B,C], d_mu/d_logvar [B,Z] (from the loss), d_zy [B,C+Z] (from
+ * the decoder).  Produces dh [B,H] and the six parameter gradients (overwritten).
+ * ws: B*(C+2Z) floats. */
+int mvh_vae_latent_bwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
+                       float p, const float* Wc, const float* Wm, const float* Wv,
+                       const float* eps, const float* y_hat, const float* logvar,
+                       const float* d_yhat, const float* d_mu, const float* d_logvar,
+                       const float* d_zy, float* dh, float* dWc, float* dbc, float* dWm,
+                       float* dbm, float* dWv, float* dbv,
+                       int32_t B, int32_t H, int32_t C, int32_t Z, void* ws, size_t ws_bytes);
+
+/* ---- row L: cheb_VAE.loss_function (cheb_VAE.py:321-346) with logpdf.KLD (logpdf.py:7-8),
+ * softclip (:24-28) and gaussian_nll (:22-23).  x_gt is fp32 (gt_f64 == 0) or fp64
+ * (gt_f64 != 0, the main.py path); rec/loss are written in that same type.
+ * loss (1 element), rec [B], kld [B] fp32, correct: one int64.  ws: mvh_vae_loss_ws_bytes(B). */
+size_t mvh_vae_loss_ws_bytes(int32_t B);
+int mvh_vae_loss_fwd(mvh_stream_t stream, const float* recon, const void* x_gt, int32_t gt_f64,
+                     const float* mu, const float* logvar, const float* y, const float* y_hat,
+                     float log_sigma, void* loss, void* rec, float* kld, int64_t* correct,
+                     int32_t B, int32_t NV /* vertices*features per mesh */, int32_t C, int32_t Z,
+                     void* ws, size_t ws_bytes);
+/* Gradients of `loss` (scaled by the upstream scalar g read from device pointer d_loss, fp32
+ * or fp64 per gt_f64; NULL means 1): d_recon [B,NV], d_mu, d_logvar [B,Z], d_yhat [B,C]. */
+int mvh_vae_loss_bwd(mvh_stream_t stream, const float* recon, const void* x_gt, int32_t gt_f64,
+                     const float* mu, const float* logvar, const float* y, const float* y_hat,
+                     float log_sigma, const void* d_loss, float* d_recon, float* d_mu,
+                     float* d_logvar, float* d_yhat, int32_t B, int32_t NV, int32_t C, int32_t Z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHVAE_HIP_H */

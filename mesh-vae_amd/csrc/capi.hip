@@ -1,0 +1,72 @@
+// C-ABI glue: error reporting, argument validation and the thin entry points
+// (propagate / pool) that map 1:1 onto the sparse kernel.
+#include "common.hpp"
+
+namespace mvh {
+
+char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_csr(const mvh_csr_t* op, const char* what) {
+  MVH_REQUIRE(op != nullptr, "%s: null CSR descriptor", what);
+  MVH_REQUIRE(op->n_rows >= 0 && op->n_cols >= 0 && op->nnz >= 0, "%s: negative CSR sizes", what);
+  MVH_REQUIRE(op->rowptr != nullptr, "%s: null rowptr", what);
+  MVH_REQUIRE(op->nnz == 0 || (op->col != nullptr && op->val != nullptr), "%s: null col/val", what);
+  return MVH_OK;
+}
+
+}  // namespace mvh
+
+using namespace mvh;
+
+extern "C" int mvh_version(void) { return 100; }
+
+extern "C" const char* mvh_last_error(void) { return last_error_buf(); }
+
+extern "C" int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len) {
+  int dev = 0;
+  MVH_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  MVH_HIP(hipGetDeviceProperties(&prop, dev));
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return MVH_OK;
+}
+
+extern "C" int mvh_spmm(mvh_stream_t stream, const mvh_csr_t* op, const float* x, float* y, const float* add,
+                        const float* z, float alpha, float beta, int32_t B, int32_t C, int32_t exact) {
+  if (int rc = check_csr(op, "spmm")) return rc;
+  MVH_REQUIRE(x && y, "spmm: null tensor");
+  MVH_REQUIRE(B >= 0 && C > 0, "spmm: bad sizes B=%d C=%d", B, C);
+  return launch_spmm((hipStream_t)stream, op, x, y, add, z, alpha, beta, B, C, exact != 0);
+}
+
+extern "C" int mvh_pool_fwd(mvh_stream_t stream, const mvh_csr_t* pool, const float* x, float* y, int32_t B,
+                            int32_t C) {
+  if (int rc = check_csr(pool, "pool_fwd")) return rc;
+  MVH_REQUIRE(x && y, "pool_fwd: null tensor");
+  MVH_REQUIRE(B >= 0 && C > 0, "pool_fwd: bad sizes B=%d C=%d", B, C);
+  return launch_spmm((hipStream_t)stream, pool, x, y, nullptr, nullptr, 1.f, 0.f, B, C, true);
+}
+
+extern "C" int mvh_pool_bwd(mvh_stream_t stream, const mvh_csr_t* pool_t, const float* dy, float* dx,
+                            int32_t B, int32_t C) {
+  if (int rc = check_csr(pool_t, "pool_bwd")) return rc;
+  MVH_REQUIRE(dy && dx, "pool_bwd: null tensor");
+  MVH_REQUIRE(B >= 0 && C > 0, "pool_bwd: bad sizes B=%d C=%d", B, C);
+  return launch_spmm((hipStream_t)stream, pool_t, dy, dx, nullptr, nullptr, 1.f, 0.f, B, C, true);
+}

@@ -1,0 +1,363 @@
+// Rows C + Q: ChebConv_batch.forward (nn/conv.py:557-577) and its analytic backward.
+//
+// Baseline ("stack") pipeline -- every stage is a separate launch over [B*N] rows:
+//   forward : T_1..T_{K-1} by K-1 sparse propagates (spmm.hip), then ONE contraction
+//             out = act([T_0|..|T_{K-1}] W + bias)            (k_cheb_contract)
+//   backward: G_k = dpre W_k^T for all k in one launch        (k_cheb_gstack)
+//             dx  = sum_k T_k(L^T) G_k by Clenshaw, in place   (spmm.hip, K-1 launches)
+//             dW_k = T_k^T dpre, db = sum dpre: register-tiled split over row chunks with
+//             per-block partials and a fixed-order final reduce (k_cheb_dw, k_reduce_partials)
+//             -- no atomics, so gradients are bitwise reproducible run to run.
+// Weights are wave-uniform and read through the scalar cache (s_load) so the inner loops are
+// v_fma with an SGPR operand; activations move as 16-byte vectors.
+#include "common.hpp"
+
+namespace mvh {
+
+// ------------------------------------------------------------------ forward contraction
+template <int COUT_T, bool FULL, bool VIN>
+__global__ void __launch_bounds__(256)
+k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ W,
+                const float* __restrict__ bias, float* __restrict__ out, long long rows, int Cin,
+                int Cout, int K, int act) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float acc[COUT_T];
+#pragma unroll
+  for (int co = 0; co < COUT_T; ++co) acc[co] = (bias && (FULL || co < Cout)) ? bias[co] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float* src = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin) + r * Cin;
+    const float* Wk = W + (long long)k * Cin * Cout;
+    if constexpr (VIN) {
+      for (int c4 = 0; c4 < Cin; c4 += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src + c4);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* w = Wk + (long long)(c4 + j) * Cout;
+#pragma unroll
+          for (int co = 0; co < COUT_T; ++co)
+            if (FULL || co < Cout) acc[co] = fmaf(tv[j], w[co], acc[co]);
+        }
+      }
+    } else {
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float t = src[ci];
+        const float* w = Wk + (long long)ci * Cout;
+#pragma unroll
+        for (int co = 0; co < COUT_T; ++co)
+          if (FULL || co < Cout) acc[co] = fmaf(t, w[co], acc[co]);
+      }
+    }
+  }
+  float* o = out + r * Cout;
+  if (act == MVH_ACT_RELU) {
+#pragma unroll
+    for (int co = 0; co < COUT_T; ++co) acc[co] = fmaxf(acc[co], 0.f);
+  }
+  if constexpr (FULL && (COUT_T % 4 == 0)) {
+#pragma unroll
+    for (int co = 0; co < COUT_T; co += 4)
+      *reinterpret_cast<float4*>(o + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+  } else {
+#pragma unroll
+    for (int co = 0; co < COUT_T; ++co)
+      if (FULL || co < Cout) o[co] = acc[co];
+  }
+}
+
+static int launch_contract(hipStream_t st, const float* x, const float* tx, const float* W,
+                           const float* bias, float* out, long long rows, int Cin, int Cout, int K,
+                           int act) {
+  const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
+  const int grid = cdiv(rows, 256);
+#define MVH_C(CT, FULL, VIN)                                                                    \
+  hipLaunchKernelGGL((k_cheb_contract<CT, FULL, VIN>), dim3(grid), dim3(256), 0, st, x, tx, W,  \
+                     bias, out, rows, Cin, Cout, K, act)
+#define MVH_CV(CT, FULL) \
+  do { if (vin) MVH_C(CT, FULL, true); else MVH_C(CT, FULL, false); } while (0)
+  if (Cout == 3) MVH_CV(3, true);
+  else if (Cout == 8) MVH_CV(8, true);
+  else if (Cout == 16) MVH_CV(16, true);
+  else if (Cout == 32) MVH_CV(32, true);
+  else if (Cout <= 8) MVH_CV(8, false);
+  else if (Cout <= 32) MVH_CV(32, false);
+  else return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: out_channels %d > 32 not supported", Cout);
+#undef MVH_CV
+#undef MVH_C
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// ------------------------------------------------------------------ backward: G_k = dpre W_k^T
+template <int COUT_T, bool FULL>
+__global__ void __launch_bounds__(256)
+k_cheb_gstack(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ W,
+              float* __restrict__ G, float* __restrict__ g0, long long rows, int Cin, int Cout, int K,
+              int act) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float dp[COUT_T];
+#pragma unroll
+  for (int co = 0; co < COUT_T; ++co) {
+    float d = 0.f;
+    if (FULL || co < Cout) {
+      d = dout[r * Cout + co];
+      if (act == MVH_ACT_RELU && !(out[r * Cout + co] > 0.f)) d = 0.f;
+    }
+    dp[co] = d;
+  }
+  for (int k = 0; k < K; ++k) {
+    // plane 0 may live in a separate buffer (dx itself when K == 1)
+    float* dst = (k == 0 ? g0 : G + (long long)k * rows * Cin) + r * Cin;
+    const float* Wk = W + (long long)k * Cin * Cout;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* w = Wk + (long long)ci * Cout;
+      float g = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT_T; ++co)
+        if (FULL || co < Cout) g = fmaf(dp[co], w[co], g);
+      dst[ci] = g;
+    }
+  }
+}
+
+static int launch_gstack(hipStream_t st, const float* dout, const float* out, const float* W, float* G,
+                         float* g0, long long rows, int Cin, int Cout, int K, int act) {
+  const int grid = cdiv(rows, 256);
+#define MVH_G(CT, FULL)                                                                          \
+  hipLaunchKernelGGL((k_cheb_gstack<CT, FULL>), dim3(grid), dim3(256), 0, st, dout, out, W, G, g0, \
+                     rows, Cin, Cout, K, act)
+  if (Cout == 3) MVH_G(3, true);
+  else if (Cout == 8) MVH_G(8, true);
+  else if (Cout == 16) MVH_G(16, true);
+  else if (Cout == 32) MVH_G(32, true);
+  else if (Cout <= 8) MVH_G(8, false);
+  else if (Cout <= 32) MVH_G(32, false);
+  else return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: out_channels %d > 32 not supported", Cout);
+#undef MVH_G
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// ------------------------------------------------------------------ backward: dW, db
+// A^T D over the row dimension: A = [T_0 | T_1 | .. | T_{K-1} | 1] (rows x KC1), D = dpre
+// (rows x Cout).  Each thread owns a 4x4 tile of the (KC1 x Cout) result; a block walks row
+// chunks of R rows staged in LDS and writes its partial tile set; blockIdx.y selects the group
+// of 256 tiles when KC1/4 * Cout/4 > 256.
+constexpr int kDwRows = 32;
+
+__global__ void __launch_bounds__(256)
+k_cheb_dw(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ dout,
+          const float* __restrict__ out, float* __restrict__ partial, long long rows, int Cin, int Cout,
+          int K, int act, int TI, int TJ, int nchunks) {
+  extern __shared__ float lds[];
+  const int KC = K * Cin;
+  const int lda = TI * 4;  // padded KC+1
+  const int ldd = TJ * 4;  // padded Cout
+  float* Tl = lds;                   // [R][lda]
+  float* Dl = lds + kDwRows * lda;   // [R][ldd]
+  const int tile = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool active = tile < TI * TJ;
+  const int ti = active ? tile / TJ : 0, tj = active ? tile % TJ : 0;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long long r0 = (long long)chunk * kDwRows;
+    const int nr = (int)min((long long)kDwRows, rows - r0);
+    __syncthreads();
+    // stage T planes: element (r, k, ci) -> Tl[r][k*Cin+ci]
+    for (int i = threadIdx.x; i < kDwRows * lda; i += blockDim.x) {
+      const int rr = i / lda, c = i % lda;
+      float v = 0.f;
+      if (rr < nr) {
+        if (c < KC) {
+          const int k = c / Cin, ci = c % Cin;
+          const float* src = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin);
+          v = src[(r0 + rr) * Cin + ci];
+        } else if (c == KC) {
+          v = 1.f;  // ones column -> db
+        }
+      }
+      Tl[i] = v;
+    }
+    for (int i = threadIdx.x; i < kDwRows * ldd; i += blockDim.x) {
+      const int rr = i / ldd, c = i % ldd;
+      float v = 0.f;
+      if (rr < nr && c < Cout) {
+        v = dout[(r0 + rr) * Cout + c];
+        if (act == MVH_ACT_RELU && !(out[(r0 + rr) * Cout + c] > 0.f)) v = 0.f;
+      }
+      Dl[i] = v;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int rr = 0; rr < kDwRows; ++rr) {
+        const float4 a = *reinterpret_cast<const float4*>(Tl + rr * lda + ti * 4);
+        const float4 d = *reinterpret_cast<const float4*>(Dl + rr * ldd + tj * 4);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], dv[j], acc[i][j]);
+      }
+    }
+  }
+  if (active) {
+    float* p = partial + (long long)blockIdx.x * (KC + 1) * Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ti * 4 + i;
+      if (row > KC) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = tj * 4 + j;
+        if (c < Cout) p[(long long)row * Cout + c] = acc[i][j];
+      }
+    }
+  }
+}
+
+// out[i] = sum_g partial[g][i] in fixed order; first n_w entries go to dW, the rest to db.
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float* __restrict__ partial, int G, int n, int n_w, float* __restrict__ dW,
+                  float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += partial[(long long)g * n + i];
+  if (i < n_w) dW[i] = s;
+  else if (db) db[i - n_w] = s;
+}
+
+static int dw_grid(long long rows) { return (int)min((long long)512, (rows + kDwRows - 1) / kDwRows); }
+
+static int launch_dw(hipStream_t st, const float* x, const float* tx, const float* dout, const float* out,
+                     float* partial, float* dW, float* db, long long rows, int Cin, int Cout, int K,
+                     int act) {
+  const int KC = K * Cin;
+  const int TI = cdiv(KC + 1, 4), TJ = cdiv(Cout, 4);
+  const int tiles = TI * TJ;
+  const int threads = min(256, cdiv(tiles, 64) * 64);
+  const int gy = cdiv(tiles, threads);
+  const int nchunks = cdiv(rows, kDwRows);
+  const int G = dw_grid(rows);
+  const size_t lds = (size_t)kDwRows * (TI * 4 + TJ * 4) * sizeof(float);
+  if (lds > 64 * 1024) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv dW: K*Cin=%d too large", KC);
+  hipLaunchKernelGGL(k_cheb_dw, dim3(G, gy), dim3(threads), lds, st, x, tx, dout, out, partial, rows, Cin,
+                     Cout, K, act, TI, TJ, nchunks);
+  MVH_LAUNCH_CHECK();
+  const int n = (KC + 1) * Cout;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, G, n, KC * Cout,
+                     dW, db);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// ------------------------------------------------------------------ host entry points
+static int tx_forward(hipStream_t st, const mvh_csr_t* lap, const float* x, float* tx, long long plane,
+                      int B, int Cin, int K) {
+  // T_1 = L x ; T_k = 2 L T_{k-1} - T_{k-2}   (nn/conv.py:564-569)
+  for (int k = 1; k < K; ++k) {
+    const float* prev = (k == 1) ? x : tx + (long long)(k - 2) * plane;
+    const float* prev2 = (k == 1) ? nullptr : (k == 2 ? x : tx + (long long)(k - 3) * plane);
+    int rc = launch_spmm(st, lap, prev, tx + (long long)(k - 1) * plane, nullptr, prev2,
+                         k == 1 ? 1.f : 2.f, -1.f, B, Cin, false);
+    if (rc) return rc;
+  }
+  return MVH_OK;
+}
+
+}  // namespace mvh
+
+using namespace mvh;
+
+extern "C" size_t mvh_cheb_conv_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
+  (void)Cout;
+  return align_up((size_t)(K > 1 ? K - 1 : 0) * B * N * Cin * sizeof(float), 256) + 256;
+}
+
+static int conv_args_ok(const mvh_csr_t* lap, int B, int N, int Cin, int Cout, int K) {
+  if (int rc = check_csr(lap, "lap")) return rc;
+  MVH_REQUIRE(B >= 0 && N >= 0 && Cin > 0 && Cout > 0, "cheb_conv: bad sizes B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
+  MVH_REQUIRE(K > 0, "cheb_conv: K must be > 0 (nn/conv.py:445)");
+  MVH_REQUIRE(lap->n_rows == N && lap->n_cols == N,
+              "cheb_conv: Laplacian is %dx%d but x has %d vertices", lap->n_rows, lap->n_cols, N);
+  return MVH_OK;
+}
+
+extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
+                                 const float* bias, float* out, float* tx_saved, int32_t B, int32_t N,
+                                 int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
+                                 size_t ws_bytes) {
+  if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
+  MVH_REQUIRE(x && W && out, "cheb_conv_fwd: null tensor");
+  if ((long long)B * N == 0) return MVH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)B * N, plane = rows * Cin;
+  float* tx = tx_saved;
+  if (!tx && K > 1) {
+    MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");
+    tx = (float*)ws;
+  }
+  if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
+  return launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act);
+}
+
+extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
+  const size_t rows = (size_t)B * N;
+  size_t tx = align_up((size_t)(K > 1 ? K - 1 : 0) * rows * Cin * sizeof(float), 256);
+  size_t g = align_up((size_t)K * rows * Cin * sizeof(float), 256);
+  size_t part = align_up((size_t)dw_grid((long long)rows) * ((size_t)K * Cin + 1) * Cout * sizeof(float), 256);
+  return tx + g + part + 256;
+}
+
+extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
+                                 const float* x, const float* W, const float* out, const float* dout,
+                                 const float* tx_saved, float* dx, float* dW, float* db, int32_t B,
+                                 int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
+                                 size_t ws_bytes) {
+  if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
+  if (int rc = check_csr(lap_t, "lap_t")) return rc;
+  MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
+  MVH_REQUIRE(x && W && dout && dW, "cheb_conv_bwd: null tensor");
+  MVH_REQUIRE(act != MVH_ACT_RELU || out, "cheb_conv_bwd: relu backward needs the forward output");
+  MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)B * N, plane = rows * Cin;
+  char* p = (char*)ws;
+  float* tx_ws = (float*)p;
+  p += align_up((size_t)(K > 1 ? K - 1 : 0) * plane * sizeof(float), 256);
+  float* G = (float*)p;
+  p += align_up((size_t)K * plane * sizeof(float), 256);
+  float* partial = (float*)p;
+  if (rows == 0) {
+    MVH_HIP(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
+    if (db) MVH_HIP(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st));
+    return MVH_OK;
+  }
+  const float* tx = tx_saved;
+  if (!tx && K > 1) {
+    if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K)) return rc;
+    tx = tx_ws;
+  }
+  if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
+  if (!dx) return MVH_OK;
+  // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
+  float* g0 = (K == 1) ? dx : G;
+  if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act)) return rc;
+  if (K == 1) return MVH_OK;
+  for (int k = K - 2; k >= 1; --k) {
+    float* bk = G + (long long)k * plane;
+    const float* bk2 = (k + 2 < K) ? G + (long long)(k + 2) * plane : nullptr;
+    if (int rc = launch_spmm(st, lap_t, G + (long long)(k + 1) * plane, bk, bk, bk2, 2.f, -1.f, B, Cin, false))
+      return rc;
+  }
+  return launch_spmm(st, lap_t, G + plane, dx, G, (K > 2) ? G + 2 * plane : nullptr, 1.f, -1.f, B, Cin, false);
+}

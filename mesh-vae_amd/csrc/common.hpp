@@ -1,0 +1,47 @@
+// Shared host-side helpers for libmeshvae_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "meshvae_hip.h"
+
+namespace mvh {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+
+#define MVH_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return ::mvh::fail(MVH_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define MVH_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      return ::mvh::fail(MVH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                         __FILE__, __LINE__);                                           \
+  } while (0)
+
+#define MVH_LAUNCH_CHECK() MVH_HIP(hipGetLastError())
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_csr(const mvh_csr_t* op, const char* what);
+
+// ---- internal launchers shared between translation units (all async on `st`)
+int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, const float* add,
+                const float* z, float alpha, float beta, int B, int C, bool exact);
+// C[M,N] = A (M x K, strides sam,sak) * Bm (K x N, strides sbk,sbn) (+bias[n]) -> act -> dropout
+int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
+                long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
+                int act, const float* drop_u, float p);
+
+}  // namespace mvh

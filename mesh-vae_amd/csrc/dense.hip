@@ -1,0 +1,312 @@
+// Dense parts of rows E/D/K/Z/R: nn.Linear (+relu +dropout), the classifier / latent heads
+// and the reparameterisation (cheb_VAE.py:203-226, 253-258, 270-280, 309-319).
+// These are skinny problems (M = batch), a few MFLOP per mesh; one LDS-tiled fp32 GEMM with
+// generic strides serves forward, dX and dW, and the latent head is one fused kernel per pass.
+#include "common.hpp"
+
+namespace mvh {
+
+// ------------------------------------------------------------------ small strided GEMM
+constexpr int TM = 32, TN = 32, TK = 32;
+
+__global__ void __launch_bounds__(256)
+k_gemm(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm,
+       long long sbk, long long sbn, float* __restrict__ C, int M, int N, int K,
+       const float* __restrict__ bias, int act, const float* __restrict__ drop_u, float p) {
+  __shared__ float As[TK][TM + 1];
+  __shared__ float Bs[TK][TN + 1];
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+  for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * 256;
+      int kk, mm;
+      if (a_kfast) { kk = e % TK; mm = e / TK; } else { mm = e % TM; kk = e / TM; }
+      const int m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+      int kb, nn;
+      if (b_nfast) { nn = e % TN; kb = e / TN; } else { kb = e % TK; nn = e / TK; }
+      const int n = n0 + nn, k2 = k0 + kb;
+      Bs[kb][nn] = (n < N && k2 < K) ? Bm[k2 * sbk + n * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < TK; ++kk) {
+      const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
+      const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+      acc[0][0] = fmaf(a0, b0, acc[0][0]);
+      acc[0][1] = fmaf(a0, b1, acc[0][1]);
+      acc[1][0] = fmaf(a1, b0, acc[1][0]);
+      acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  const float keep_scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+      if (m >= M || n >= N) continue;
+      float v = acc[i][j];
+      if (bias) v += bias[n];
+      if (act == MVH_ACT_RELU) v = fmaxf(v, 0.f);
+      if (drop_u && p > 0.f) v = (drop_u[(long long)m * N + n] >= p) ? v * keep_scale : 0.f;
+      C[(long long)m * N + n] = v;
+    }
+}
+
+int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
+                long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
+                int act, const float* drop_u, float p) {
+  if (M == 0 || N == 0) return MVH_OK;
+  hipLaunchKernelGGL(k_gemm, dim3(cdiv(N, TN), cdiv(M, TM)), dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn,
+                     C, M, N, K, bias, act, drop_u, p);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// dpre = dy masked by the forward output (relu and/or dropout zeroes) and rescaled by 1/(1-p)
+__global__ void __launch_bounds__(256)
+k_linear_dpre(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dpre,
+              long long n, int masked, float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float d = dy[i];
+  if (masked) d = (y[i] > 0.f) ? d * scale : 0.f;
+  dpre[i] = d;
+}
+
+__global__ void __launch_bounds__(256)
+k_colsum(const float* __restrict__ a, float* __restrict__ out, int M, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += a[(long long)m * N + n];
+  out[n] = s;
+}
+
+// ------------------------------------------------------------------ latent head, forward
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const float* __restrict__ drop_u,
+             float p, const float* __restrict__ Wc, const float* __restrict__ bc,
+             const float* __restrict__ Wm, const float* __restrict__ bm, const float* __restrict__ Wv,
+             const float* __restrict__ bv, const float* __restrict__ eps, float* __restrict__ y_hat,
+             float* __restrict__ mu, float* __restrict__ logvar, float* __restrict__ z,
+             float* __restrict__ zy, int H, int C, int Z) {
+  extern __shared__ float lds[];
+  float* hy = lds;            // [C+H]  = cat[y, h]                      (cheb_VAE.py:209)
+  float* hd = lds + C + H;    // [H]    = classifier's dropout(h)        (cheb_VAE.py:255)
+  float* outs = hd + H;       // [C+2Z] logits | mu | logvar
+  const int b = blockIdx.x;
+  const float scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    const float v = h[(long long)b * H + j];
+    hy[C + j] = v;
+    hd[j] = (drop_u && p > 0.f) ? ((drop_u[(long long)b * H + j] >= p) ? v * scale : 0.f) : v;
+  }
+  for (int j = threadIdx.x; j < C; j += blockDim.x) hy[j] = y[(long long)b * C + j];
+  __syncthreads();
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, nw = blockDim.x / 64;
+  for (int o = wave; o < C + 2 * Z; o += nw) {
+    float s = 0.f;
+    if (o < C) {
+      const float* w = Wc + (long long)o * H;
+      for (int j = lane; j < H; j += 64) s = fmaf(hd[j], w[j], s);
+      s = wave_sum(s);
+      if (lane == 0) outs[o] = s + bc[o];
+    } else {
+      const int zz = (o - C) % Z;
+      const bool is_mu = (o - C) < Z;
+      const float* w = (is_mu ? Wm : Wv) + (long long)zz * (C + H);
+      for (int j = lane; j < C + H; j += 64) s = fmaf(hy[j], w[j], s);
+      s = wave_sum(s);
+      if (lane == 0) outs[o] = s + (is_mu ? bm[zz] : bv[zz]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // softmax over the C logits (cheb_VAE.py:256)
+    float mx = outs[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, outs[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(outs[c] - mx);
+    for (int c = 0; c < C; ++c) y_hat[(long long)b * C + c] = expf(outs[c] - mx) / den;
+  }
+  for (int t = threadIdx.x; t < Z; t += blockDim.x) {
+    const float m = outs[C + t], lv = outs[C + Z + t];
+    // reparameterize (cheb_VAE.py:309-319) or z = mu in test mode (:221)
+    const float zz = eps ? fmaf(eps[(long long)b * Z + t], expf(lv * 0.5f), m) : m;
+    mu[(long long)b * Z + t] = m;
+    logvar[(long long)b * Z + t] = lv;
+    z[(long long)b * Z + t] = zz;
+    zy[(long long)b * (C + Z) + C + t] = zz;
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) zy[(long long)b * (C + Z) + c] = hy[c];
+}
+
+// ------------------------------------------------------------------ latent head, backward
+__global__ void __launch_bounds__(256)
+k_latent_bwd(const float* __restrict__ drop_u, float p, const float* __restrict__ Wc,
+             const float* __restrict__ Wm, const float* __restrict__ Wv, const float* __restrict__ eps,
+             const float* __restrict__ y_hat, const float* __restrict__ logvar,
+             const float* __restrict__ d_yhat, const float* __restrict__ d_mu,
+             const float* __restrict__ d_logvar, const float* __restrict__ d_zy, float* __restrict__ dh,
+             float* __restrict__ dpre, int H, int C, int Z) {
+  extern __shared__ float lds[];
+  float* g = lds;  // [C+2Z]: dlogit | dmu | dlogvar
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(d_yhat[(long long)b * C + c], y_hat[(long long)b * C + c], s);
+    for (int c = 0; c < C; ++c)
+      g[c] = y_hat[(long long)b * C + c] * (d_yhat[(long long)b * C + c] - s);
+  }
+  for (int t = threadIdx.x; t < Z; t += blockDim.x) {
+    const float dz = d_zy[(long long)b * (C + Z) + C + t];
+    float dm = d_mu[(long long)b * Z + t] + dz;
+    float dl = d_logvar[(long long)b * Z + t];
+    if (eps) dl = fmaf(dz * eps[(long long)b * Z + t], 0.5f * expf(0.5f * logvar[(long long)b * Z + t]), dl);
+    g[C + t] = dm;
+    g[C + Z + t] = dl;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C + 2 * Z; o += blockDim.x) dpre[(long long)b * (C + 2 * Z) + o] = g[o];
+  const float scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(g[c], Wc[(long long)c * H + j], a);
+    if (drop_u && p > 0.f) a = (drop_u[(long long)b * H + j] >= p) ? a * scale : 0.f;
+    for (int t = 0; t < Z; ++t) {
+      a = fmaf(g[C + t], Wm[(long long)t * (C + H) + C + j], a);
+      a = fmaf(g[C + Z + t], Wv[(long long)t * (C + H) + C + j], a);
+    }
+    dh[(long long)b * H + j] = a;
+  }
+}
+
+// parameter gradients of the three heads: thread (o, j); j == ld is the bias slot
+__global__ void __launch_bounds__(256)
+k_latent_wgrad(const float* __restrict__ h, const float* __restrict__ y, const float* __restrict__ drop_u,
+               float p, const float* __restrict__ dpre, float* __restrict__ dWc, float* __restrict__ dbc,
+               float* __restrict__ dWm, float* __restrict__ dbm, float* __restrict__ dWv,
+               float* __restrict__ dbv, int B, int H, int C, int Z) {
+  const int ld = C + H;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (j > ld) return;
+  const int no = C + 2 * Z;
+  const float scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+  float s = 0.f;
+  if (o < C) {
+    if (j > H) return;  // classifier input is only [H] (+ bias slot at j == H)
+    for (int b = 0; b < B; ++b) {
+      float in = 1.f;
+      if (j < H) {
+        in = h[(long long)b * H + j];
+        if (drop_u && p > 0.f) in = (drop_u[(long long)b * H + j] >= p) ? in * scale : 0.f;
+      }
+      s = fmaf(dpre[(long long)b * no + o], in, s);
+    }
+    if (j < H) dWc[(long long)o * H + j] = s; else dbc[o] = s;
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const float in = (j == ld) ? 1.f : (j < C ? y[(long long)b * C + j] : h[(long long)b * H + (j - C)]);
+      s = fmaf(dpre[(long long)b * no + o], in, s);
+    }
+    const int zz = (o - C) % Z;
+    const bool is_mu = (o - C) < Z;
+    if (j < ld) (is_mu ? dWm : dWv)[(long long)zz * ld + j] = s;
+    else (is_mu ? dbm : dbv)[zz] = s;
+  }
+}
+
+}  // namespace mvh
+
+using namespace mvh;
+
+extern "C" int mvh_linear_fwd(mvh_stream_t stream, const float* x, const float* W, const float* bias,
+                              float* y, int32_t B, int32_t in_f, int32_t out_f, int32_t act,
+                              const float* drop_u, float p) {
+  MVH_REQUIRE(x && W && y, "linear_fwd: null tensor");
+  MVH_REQUIRE(B >= 0 && in_f > 0 && out_f > 0, "linear_fwd: bad sizes");
+  MVH_REQUIRE(p >= 0.f && p < 1.f, "linear_fwd: dropout p=%f out of range", p);
+  // y[b,o] = sum_i x[b,i] W[o,i]
+  return launch_gemm((hipStream_t)stream, x, in_f, 1, W, 1, in_f, y, B, out_f, in_f, bias, act, drop_u, p);
+}
+
+extern "C" int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* W, const float* y,
+                              const float* dy, float* dx, float* dW, float* db, int32_t B, int32_t in_f,
+                              int32_t out_f, int32_t act, float p, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(x && W && dy && dW, "linear_bwd: null tensor");
+  MVH_REQUIRE(ws && ws_bytes >= (size_t)B * out_f * sizeof(float), "linear_bwd: workspace too small");
+  const bool masked = (act == MVH_ACT_RELU);
+  MVH_REQUIRE(masked || p == 0.f, "linear_bwd: dropout without relu is not supported");
+  MVH_REQUIRE(!masked || y, "linear_bwd: relu/dropout backward needs the forward output");
+  hipStream_t st = (hipStream_t)stream;
+  float* dpre = (float*)ws;
+  const long long n = (long long)B * out_f;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_linear_dpre, dim3(cdiv(n, 256)), dim3(256), 0, st, dy, y, dpre, n, masked ? 1 : 0,
+                       p > 0.f ? 1.f / (1.f - p) : 1.f);
+    MVH_LAUNCH_CHECK();
+  }
+  if (dx)  // dx[b,i] = sum_o dpre[b,o] W[o,i]
+    if (int rc = launch_gemm(st, dpre, out_f, 1, W, in_f, 1, dx, B, in_f, out_f, nullptr, 0, nullptr, 0.f)) return rc;
+  // dW[o,i] = sum_b dpre[b,o] x[b,i]
+  if (int rc = launch_gemm(st, dpre, 1, out_f, x, in_f, 1, dW, out_f, in_f, B, nullptr, 0, nullptr, 0.f)) return rc;
+  if (db) {
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(out_f, 256)), dim3(256), 0, st, dpre, db, B, out_f);
+    MVH_LAUNCH_CHECK();
+  }
+  return MVH_OK;
+}
+
+extern "C" int mvh_vae_latent_fwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
+                                  float p, const float* Wc, const float* bc, const float* Wm,
+                                  const float* bm, const float* Wv, const float* bv, const float* eps,
+                                  float* y_hat, float* mu, float* logvar, float* z, float* zy, int32_t B,
+                                  int32_t H, int32_t C, int32_t Z) {
+  MVH_REQUIRE(h && y && Wc && bc && Wm && bm && Wv && bv && y_hat && mu && logvar && z && zy, "latent_fwd: null tensor");
+  MVH_REQUIRE(H > 0 && C > 0 && Z > 0 && B >= 0, "latent_fwd: bad sizes");
+  MVH_REQUIRE(p >= 0.f && p < 1.f, "latent_fwd: dropout p out of range");
+  if (B == 0) return MVH_OK;
+  const size_t lds = (size_t)(C + H + H + C + 2 * Z) * sizeof(float);
+  MVH_REQUIRE(lds <= 64 * 1024, "latent_fwd: hidden size %d too large", H);
+  hipLaunchKernelGGL(k_latent_fwd, dim3(B), dim3(256), lds, (hipStream_t)stream, h, y, drop_u, p, Wc, bc, Wm,
+                     bm, Wv, bv, eps, y_hat, mu, logvar, z, zy, H, C, Z);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+extern "C" int mvh_vae_latent_bwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
+                                  float p, const float* Wc, const float* Wm, const float* Wv,
+                                  const float* eps, const float* y_hat, const float* logvar,
+                                  const float* d_yhat, const float* d_mu, const float* d_logvar,
+                                  const float* d_zy, float* dh, float* dWc, float* dbc, float* dWm,
+                                  float* dbm, float* dWv, float* dbv, int32_t B, int32_t H, int32_t C,
+                                  int32_t Z, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(h && y && Wc && Wm && Wv && y_hat && logvar && d_yhat && d_mu && d_logvar && d_zy && dh &&
+                  dWc && dbc && dWm && dbm && dWv && dbv, "latent_bwd: null tensor");
+  const int no = C + 2 * Z;
+  MVH_REQUIRE(ws && ws_bytes >= (size_t)B * no * sizeof(float), "latent_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* dpre = (float*)ws;
+  if (B > 0) {
+    hipLaunchKernelGGL(k_latent_bwd, dim3(B), dim3(256), (size_t)no * sizeof(float), st, drop_u, p, Wc, Wm, Wv,
+                       eps, y_hat, logvar, d_yhat, d_mu, d_logvar, d_zy, dh, dpre, H, C, Z);
+    MVH_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_latent_wgrad, dim3(cdiv(C + H + 1, 256), no), dim3(256), 0, st, h, y, drop_u, p, dpre,
+                     dWc, dbc, dWm, dbm, dWv, dbv, B, H, C, Z);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}

@@ -1,0 +1,179 @@
+// Row L: cheb_VAE.loss_function (cheb_VAE.py:321-346) = KLD (logpdf.py:7-8) + Gaussian NLL with
+// the soft-clipped constant log-sigma (logpdf.py:22-28) - 2 log q(y), fused into two launches
+// forward (per-mesh partial sums in fp64, then a one-block finish) and one launch backward.
+// x_gt arrives as fp64 from main.py (data.py:107) and fp32 from inference.py:87; the reference's
+// type promotion makes rec/loss fp64 in the first case, which is reproduced here.
+#include "common.hpp"
+
+namespace mvh {
+
+constexpr int kLossSplit = 16;  // blocks per mesh for the reconstruction sum
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_loss_partial(const float* __restrict__ recon, const GT* __restrict__ gt, double inv_sigma,
+               double* __restrict__ partial, int NV) {
+  const int b = blockIdx.y, s = blockIdx.x;
+  const long long base = (long long)b * NV;
+  double acc = 0.0;
+  for (int i = s * blockDim.x + threadIdx.x; i < NV; i += gridDim.x * blockDim.x) {
+    double d;
+    if constexpr (sizeof(GT) == 8) {
+      d = ((double)gt[base + i] - (double)recon[base + i]) * inv_sigma;
+    } else {  // fp32 path: the reference subtracts and divides in fp32
+      const float df = (gt[base + i] - recon[base + i]) / (float)(1.0 / inv_sigma);
+      d = (double)df;
+    }
+    acc += 0.5 * d * d;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(long long)b * gridDim.x + s] = red[0];
+}
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_loss_finish(const double* __restrict__ partial, const float* __restrict__ mu,
+              const float* __restrict__ logvar, const float* __restrict__ y,
+              const float* __restrict__ y_hat, double elem_const, GT* __restrict__ loss,
+              GT* __restrict__ rec, float* __restrict__ kld, long long* __restrict__ correct, int B,
+              int NV, int C, int Z, int S) {
+  __shared__ double red[256];
+  __shared__ int redc[256];
+  double tot = 0.0;
+  int corr = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    double r = 0.0;
+    for (int s = 0; s < S; ++s) r += partial[(long long)b * S + s];
+    r += (double)NV * elem_const;
+    float k = 0.f;
+    for (int t = 0; t < Z; ++t) {
+      const float m = mu[(long long)b * Z + t], lv = logvar[(long long)b * Z + t];
+      k += 1.f + lv - m * m - expf(lv);
+    }
+    k *= -0.5f;
+    float q = 0.f;
+    int am_hat = 0, am_y = 0;
+    for (int c = 0; c < C; ++c) {
+      const float yh = y_hat[(long long)b * C + c], yy = y[(long long)b * C + c];
+      q = fmaf(yh, yy, q);
+      if (yh > y_hat[(long long)b * C + am_hat]) am_hat = c;
+      if (yy > y[(long long)b * C + am_y]) am_y = c;
+    }
+    const GT rec_t = (GT)r;
+    rec[b] = rec_t;
+    kld[b] = k;
+    tot += (double)((GT)k + rec_t - (GT)2 * (GT)logf(q));
+    corr += (am_hat == am_y) ? 1 : 0;
+  }
+  red[threadIdx.x] = tot;
+  redc[threadIdx.x] = corr;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[threadIdx.x] += red[threadIdx.x + off];
+      redc[threadIdx.x] += redc[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = (GT)(red[0] / (double)B);
+    correct[0] = (long long)redc[0];
+  }
+}
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_loss_bwd_recon(const float* __restrict__ recon, const GT* __restrict__ gt, const GT* __restrict__ d_loss,
+                 double inv_var_over_B, float* __restrict__ d_recon, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double g = d_loss ? (double)d_loss[0] : 1.0;
+  d_recon[i] = (float)(g * inv_var_over_B * ((double)recon[i] - (double)gt[i]));
+}
+
+template <typename GT>
+__global__ void __launch_bounds__(256)
+k_loss_bwd_small(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ y,
+                 const float* __restrict__ y_hat, const GT* __restrict__ d_loss, float* __restrict__ d_mu,
+                 float* __restrict__ d_logvar, float* __restrict__ d_yhat, int B, int C, int Z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float g = (float)((d_loss ? (double)d_loss[0] : 1.0) / (double)B);
+  if (i < B * Z) {
+    d_mu[i] = g * mu[i];
+    d_logvar[i] = g * (-0.5f) * (1.f - expf(logvar[i]));
+  }
+  if (i < B) {
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) q = fmaf(y_hat[(long long)i * C + c], y[(long long)i * C + c], q);
+    for (int c = 0; c < C; ++c) d_yhat[(long long)i * C + c] = g * (-2.f) * y[(long long)i * C + c] / q;
+  }
+}
+
+}  // namespace mvh
+
+using namespace mvh;
+
+extern "C" size_t mvh_vae_loss_ws_bytes(int32_t B) { return (size_t)B * kLossSplit * sizeof(double) + 256; }
+
+extern "C" int mvh_vae_loss_fwd(mvh_stream_t stream, const float* recon, const void* x_gt, int32_t gt_f64,
+                                const float* mu, const float* logvar, const float* y, const float* y_hat,
+                                float log_sigma, void* loss, void* rec, float* kld, int64_t* correct,
+                                int32_t B, int32_t NV, int32_t C, int32_t Z, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(recon && x_gt && mu && logvar && y && y_hat && loss && rec && kld && correct, "loss_fwd: null tensor");
+  MVH_REQUIRE(B > 0 && NV > 0 && C > 0 && Z > 0, "loss_fwd: bad sizes");
+  MVH_REQUIRE(ws && ws_bytes >= (size_t)B * kLossSplit * sizeof(double), "loss_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  // exp(log_sigma) in the precision the reference uses (fp32 tensor; cheb_VAE.py:329-330)
+  const double sigma = (double)expf(log_sigma);
+  const double elem_const = (double)(float)log_sigma + 0.5 * 1.8378770664093453 /* ln(2 pi) */;
+  if (gt_f64) {
+    hipLaunchKernelGGL((k_loss_partial<double>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const double*)x_gt,
+                       1.0 / sigma, partial, NV);
+    MVH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_loss_finish<double>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
+                       elem_const, (double*)loss, (double*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit);
+  } else {
+    hipLaunchKernelGGL((k_loss_partial<float>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const float*)x_gt,
+                       1.0 / sigma, partial, NV);
+    MVH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_loss_finish<float>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
+                       elem_const, (float*)loss, (float*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit);
+  }
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+extern "C" int mvh_vae_loss_bwd(mvh_stream_t stream, const float* recon, const void* x_gt, int32_t gt_f64,
+                                const float* mu, const float* logvar, const float* y, const float* y_hat,
+                                float log_sigma, const void* d_loss, float* d_recon, float* d_mu,
+                                float* d_logvar, float* d_yhat, int32_t B, int32_t NV, int32_t C, int32_t Z) {
+  MVH_REQUIRE(recon && x_gt && mu && logvar && y && y_hat && d_recon && d_mu && d_logvar && d_yhat, "loss_bwd: null tensor");
+  MVH_REQUIRE(B > 0 && NV > 0 && C > 0 && Z > 0, "loss_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const double sigma = (double)expf(log_sigma);
+  const double ivb = 1.0 / (sigma * sigma) / (double)B;
+  const long long n = (long long)B * NV;
+  const int small = max(B * Z, B);
+  if (gt_f64) {
+    hipLaunchKernelGGL((k_loss_bwd_recon<double>), dim3(cdiv(n, 256)), dim3(256), 0, st, recon, (const double*)x_gt,
+                       (const double*)d_loss, ivb, d_recon, n);
+    MVH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_loss_bwd_small<double>), dim3(cdiv(small, 256)), dim3(256), 0, st, mu, logvar, y, y_hat,
+                       (const double*)d_loss, d_mu, d_logvar, d_yhat, B, C, Z);
+  } else {
+    hipLaunchKernelGGL((k_loss_bwd_recon<float>), dim3(cdiv(n, 256)), dim3(256), 0, st, recon, (const float*)x_gt,
+                       (const float*)d_loss, ivb, d_recon, n);
+    MVH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_loss_bwd_small<float>), dim3(cdiv(small, 256)), dim3(256), 0, st, mu, logvar, y, y_hat,
+                       (const float*)d_loss, d_mu, d_logvar, d_yhat, B, C, Z);
+  }
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}

@@ -1,0 +1,75 @@
+"""ctypes binding of libmeshvae_hip.so -- the C ABI declared in include/meshvae_hip.h.
+
+There is no CPU fallback: every op in this package launches hand-written HIP kernels on
+an MI355X.  If the shared library is missing, or a tensor is not a contiguous CUDA(HIP)
+tensor, the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeshvae_hip.so")
+_lib = None
+
+
+class MeshVaeHipError(RuntimeError):
+    pass
+
+
+class CsrStruct(ctypes.Structure):
+    """mvh_csr_t"""
+    _fields_ = [("n_rows", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("nnz", ctypes.c_int32),
+                ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p)]
+
+
+_P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
+_CSR = ctypes.POINTER(CsrStruct)
+
+# name -> (restype, argtypes); must list EVERY symbol of include/meshvae_hip.h (tests check it)
+SIGNATURES = {
+    "mvh_version": (ctypes.c_int, []),
+    "mvh_last_error": (ctypes.c_char_p, []),
+    "mvh_device_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]),
+    "mvh_spmm": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _F, _F, _I, _I, _I]),
+    "mvh_pool_fwd": (ctypes.c_int, [_P, _CSR, _P, _P, _I, _I]),
+    "mvh_pool_bwd": (ctypes.c_int, [_P, _CSR, _P, _P, _I, _I]),
+    "mvh_cheb_conv_ws_bytes": (_Z, [_I] * 5),
+    "mvh_cheb_conv_fwd": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _Z]),
+    "mvh_cheb_conv_bwd_ws_bytes": (_Z, [_I] * 5),
+    "mvh_cheb_conv_bwd": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 6 + [_P, _Z]),
+    "mvh_linear_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F]),
+    "mvh_linear_bwd": (ctypes.c_int, [_P] * 8 + [_I] * 4 + [_F, _P, _Z]),
+    "mvh_vae_latent_fwd": (ctypes.c_int, [_P, _P, _P, _P, _F] + [_P] * 12 + [_I] * 4),
+    "mvh_vae_latent_bwd": (ctypes.c_int, [_P, _P, _P, _P, _F] + [_P] * 17 + [_I] * 4 + [_P, _Z]),
+    "mvh_vae_loss_ws_bytes": (_Z, [_I]),
+    "mvh_vae_loss_fwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 4 + [_P, _Z]),
+    "mvh_vae_loss_bwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 4),
+}
+
+
+def lib():
+    """Load libmeshvae_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MeshVaeHipError(
+                f"{LIB_PATH} is missing: build it with `make -C mesh-vae_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MeshVaeHipError(f"libmeshvae_hip error {rc}: {lib().mvh_last_error().decode()}")
+
+
+def device_info():
+    n_cu, lds = ctypes.c_int(0), ctypes.c_int(0)
+    arch = ctypes.create_string_buffer(64)
+    check(lib().mvh_device_info(ctypes.byref(n_cu), ctypes.byref(lds), arch, 64))
+    return {"n_cu": n_cu.value, "lds_bytes_per_cu": lds.value, "arch": arch.value.decode()}

@@ -1,0 +1,89 @@
+"""Fixed-topology preprocessing: the reference's COO edge lists -> device CSR.
+
+The reference hands the model *uncoalesced* COO tensors (model.py:24-32) and walks them
+edge by edge every call (nn/conv.py:199-200, :363).  Here each operator is converted once
+into CSR over output rows (stable, so a row keeps the reference's edge order and therefore
+its fp32 accumulation order) plus the CSR of its transpose for the backward pass, int32
+indices, uploaded once and cached for the life of the tensors.
+"""
+import ctypes
+
+import torch
+
+from . import CsrStruct
+
+
+class Csr:
+    """One CSR operator resident on the device + its mvh_csr_t descriptor."""
+
+    def __init__(self, out_idx, in_idx, val, n_rows, n_cols, device):
+        out_idx = out_idx.detach().to("cpu", torch.int64)
+        in_idx = in_idx.detach().to("cpu", torch.int64)
+        val = val.detach().to("cpu", torch.float32)
+        if out_idx.numel():
+            if int(out_idx.min()) < 0 or int(out_idx.max()) >= n_rows:
+                raise ValueError(f"sparse operator row index out of range [0, {n_rows})")
+            if int(in_idx.min()) < 0 or int(in_idx.max()) >= n_cols:
+                raise ValueError(f"sparse operator column index out of range [0, {n_cols})")
+        order = torch.sort(out_idx, stable=True).indices
+        counts = torch.bincount(out_idx, minlength=n_rows)
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(out_idx.numel())
+        self.max_row_nnz = int(counts.max()) if counts.numel() else 0
+        self.rowptr = rowptr.to(torch.int32).to(device)
+        self.col = in_idx[order].to(torch.int32).to(device)
+        self.val = val[order].contiguous().to(device)
+        self.struct = CsrStruct(self.n_rows, self.n_cols, self.nnz, self.rowptr.data_ptr(),
+                                self.col.data_ptr(), self.val.data_ptr())
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+class Operator:
+    """A sparse operator y = P x together with P^T (for the backward pass)."""
+
+    def __init__(self, out_idx, in_idx, val, n_out, n_in, device):
+        self.fwd = Csr(out_idx, in_idx, val, n_out, n_in, device)
+        self.bwd = Csr(in_idx, out_idx, val, n_in, n_out, device)
+        self.n_out, self.n_in = int(n_out), int(n_in)
+
+
+_cache = {}
+
+
+def _key(*tensors, extra=()):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors) + tuple(extra)
+
+
+def laplacian(edge_index, norm, num_nodes):
+    """CSR of the propagate of ChebConv_batch (flow source_to_target, nn/conv.py:172):
+    gather at edge_index[0], sum at edge_index[1]; square [num_nodes, num_nodes] with
+    empty rows where the edge list does not reach (cheb_VAE.py:288)."""
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.long:
+        raise ValueError("`edge_index` must be a torch.LongTensor of shape [2, num_messages]")
+    k = _key(edge_index, norm, extra=(int(num_nodes),))
+    hit = _cache.get(k)
+    if hit is None:
+        op = Operator(edge_index[1], edge_index[0], norm, num_nodes, num_nodes, norm.device)
+        hit = _cache[k] = (op, edge_index, norm)   # keep the tensors alive: data_ptr is the key
+    return hit[0]
+
+
+def pool_operator(pool_mat):
+    """CSR of SurfacePool's propagate (flow target_to_source, nn/pool.py:15,19):
+    out row = indices[0], gathered input row = indices[1], size = pool_mat.size()."""
+    idx, val = pool_mat._indices(), pool_mat._values()
+    k = _key(idx, val, extra=tuple(pool_mat.size()))
+    hit = _cache.get(k)
+    if hit is None:
+        n_out, n_in = pool_mat.size()
+        op = Operator(idx[0], idx[1], val, n_out, n_in, val.device)
+        hit = _cache[k] = (op, idx, val)
+    return hit[0]
+
+
+def clear_cache():
+    _cache.clear()

@@ -1,0 +1,65 @@
+"""`model` -- model factory with the reference's signature (reference model.py:24-118).
+
+`get_model(config, device, model_type=None, save_init=True)` builds the A/D/U hierarchy of
+the template, converts it to the same uncoalesced torch sparse COO tensors the reference
+hands to the model (model.py:24-32, 44-46), instantiates `cheb_VAE`, prints the parameter
+table and saves `initial_weight.pt` -- the caller-visible side effects of model.py:56-60.
+
+Hierarchy source: the reference generates it with psbody/open3d host code
+(mesh_operations.py), which is outside the hot path (SURVEY.md section 8(f) "next" #1) and not
+installable here.  Until that row is built, `config['topology']` must name an .npz holding
+the precomputed hierarchy (format of tests/golden/topology_5k.npz, produced from the
+reference's own generator by oracle/make_golden.py).
+"""
+import os
+
+import numpy as np
+import torch
+
+from models.cheb_VAE import cheb_VAE
+
+
+def scipy_to_torch_sparse(scp_matrix):
+    """scipy COO -> torch sparse COO, order of entries preserved (reference model.py:24-32)."""
+    idx = torch.from_numpy(np.vstack((scp_matrix.row, scp_matrix.col)).astype(np.int64))
+    val = torch.from_numpy(np.asarray(scp_matrix.data, dtype=np.float32))
+    return torch.sparse_coo_tensor(idx, val, torch.Size(scp_matrix.shape), check_invariants=False)
+
+
+def _coo(row, col, val, shape, device):
+    idx = torch.from_numpy(np.vstack((row, col)).astype(np.int64))
+    v = torch.from_numpy(np.asarray(val, dtype=np.float32))
+    return torch.sparse_coo_tensor(idx, v, torch.Size([int(s) for s in shape]), check_invariants=False).to(device)
+
+
+def load_topology(path, device):
+    """(D_t, U_t, A_t, num_nodes) from a hierarchy .npz, as sparse COO tensors on `device`."""
+    npz = np.load(path, allow_pickle=False)
+    num_nodes = [int(v) for v in npz["num_nodes"]]
+    n = len(num_nodes)
+    A_t = [_coo(npz[f"A{i}_row"], npz[f"A{i}_col"], npz[f"A{i}_val"], (num_nodes[i],) * 2, device) for i in range(n)]
+    D_t = [_coo(npz[f"D{i}_row"], npz[f"D{i}_col"], npz[f"D{i}_val"], npz[f"D{i}_shape"], device) for i in range(n - 1)]
+    U_t = [_coo(npz[f"U{i}_row"], npz[f"U{i}_col"], npz[f"U{i}_val"], npz[f"U{i}_shape"], device) for i in range(n - 1)]
+    return D_t, U_t, A_t, num_nodes
+
+
+def get_model(config, device, model_type=None, save_init=True):
+    topo = config.get('topology')
+    if not topo:
+        raise NotImplementedError(
+            "get_model: on-the-fly hierarchy generation (reference mesh_operations.py) is not built yet; "
+            "set config['topology'] to a precomputed hierarchy .npz (see oracle/make_golden.py)")
+    D_t, U_t, A_t, num_nodes = load_topology(topo, device)
+    num_feature = int(config.get('num_features', 3))
+    if model_type is None:
+        model_type = config['type']
+    if model_type != 'cheb_VAE':
+        raise NotImplementedError(f"model type {model_type!r} is outside the hot path (only cheb_VAE is built)")
+    print('Using model: cheb_VAE')
+    net = cheb_VAE(num_feature, config, D_t, U_t, A_t, num_nodes, model=config.get('model', 'MSE_VAE')).to(device)
+    for name, parameters in net.named_parameters():
+        print(name, ':', parameters.size())
+    if save_init:
+        os.makedirs(config['checkpoint_dir'], exist_ok=True)
+        torch.save(net.state_dict(), os.path.join(config['checkpoint_dir'], 'initial_weight.pt'))
+    return net

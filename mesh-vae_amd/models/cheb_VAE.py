@@ -1,0 +1,160 @@
+"""`models.cheb_VAE` -- MI355X-native conditional mesh VAE with the reference's API.
+
+Same constructor, attributes, method names, return tuples and state_dict layout as the
+reference class (models/cheb_VAE.py:104-351) so main.py / inference.py / crecon.py run
+unchanged, but every stage executes hand-written HIP kernels from libmeshvae_hip:
+
+  encoder   4 x [ChebConv+ReLU (fused) -> one-hot downsample gather] -> enc_lin+ReLU+dropout
+  head      classifier softmax, z_mean / z_log_var, reparameterisation   (one fused kernel)
+  decoder   dec_lin, dec_lin_2 (+ReLU+dropout) -> 4 x [barycentric upsample -> ChebConv+ReLU]
+            -> final ChebConv on the coarsest edge list (the reference's quirk, :288)
+  loss      KLD + Gaussian NLL(fixed sigma) - 2 log q(y)                   (fused kernels)
+
+Topology (A/D/U) is converted once to device CSR at construction.  Parameters are created
+in the reference's order, so `torch.manual_seed(s)` yields bit-identical initial weights.
+The unused pieces of the reference file (EqualLR, AdaIN, binary_cross_entropy) are dead code
+there and are not reproduced.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from meshvae_hip import functional as F_hip
+from meshvae_hip import topology
+from nn.conv import ChebConv_batch
+from nn.pool import SurfacePool
+
+# log_sigma = softclip(1, -6) = -6 + softplus(7): a constant (cheb_VAE.py:329-330, logpdf.py:24-28)
+LOG_SIGMA = float(torch.nn.functional.softplus(torch.tensor([7.0])) - 6.0)
+
+
+class cheb_VAE(torch.nn.Module):
+
+    def __init__(self, num_features, config, downsample_matrices, upsample_matrices,
+                 adjacency_matrices, num_nodes, model='MSE_VAE'):
+        super().__init__()
+        self.n_layers = config['n_layers']
+        self.filters = [num_features] + list(config['num_conv_filters'])
+        self.K = config['polygon_order']
+        self.downsample_matrices = downsample_matrices
+        self.upsample_matrices = upsample_matrices
+        self.adjacency_matrices = adjacency_matrices
+        levels = [ChebConv_batch.norm(adjacency_matrices[i]._indices(), num_nodes[i])
+                  for i in range(len(num_nodes))]
+        self.A_edge_index, self.A_norm = zip(*levels)
+        self.num_nodes = list(num_nodes)
+
+        f = self.filters
+        # creation order == RNG order of the reference (encoder convs, decoder convs, linears)
+        self.cheb = nn.ModuleList(ChebConv_batch(f[i], f[i + 1], self.K[i]) for i in range(len(f) - 2))
+        self.cheb_dec = nn.ModuleList(ChebConv_batch(f[-i - 1], f[-i - 2], self.K[i]) for i in range(len(f) - 1))
+        self.cheb_dec[-1].bias = None          # last conv has no bias (its draw is discarded)
+        self.pool = SurfacePool()
+
+        self.num_class = config['num_classes']
+        self.z = config['num_style']
+        self.num_hidden = config['num_hidden']
+        flat = self.downsample_matrices[-1].shape[0] * f[-1]
+        self.classifier_layer = nn.Linear(self.num_hidden, self.num_class)
+        self.z_mean = nn.Linear(self.num_hidden + self.num_class, self.z)
+        self.z_log_var = nn.Linear(self.num_hidden + self.num_class, self.z)
+        self.enc_lin = nn.Linear(flat, self.num_hidden)
+        self.dec_lin = nn.Linear(self.z + self.num_class, self.num_hidden)
+        self.dec_lin_1 = nn.Linear(self.z + self.num_class, self.num_hidden)   # unused, kept for state_dict
+        self.dec_lin_2 = nn.Linear(self.num_hidden, flat)
+        self.dropout = nn.Dropout(p=config['dropout'])
+        self.reset_parameters()
+        self.type = model
+        self._ops_ready = False
+
+    # ------------------------------------------------------------------ topology
+    def _prepare(self):
+        """Device CSR of every A / D / U level (built once; tensors are immutable inputs)."""
+        if self._ops_ready:
+            return
+        n = self.n_layers
+        self._lap = [topology.laplacian(self.A_edge_index[i], self.A_norm[i], self.num_nodes[i]) for i in range(n)]
+        # final layer: coarsest edge list applied to the finest vertex set (reference :288)
+        self._lap_final = topology.laplacian(self.A_edge_index[-1], self.A_norm[-1], self.num_nodes[0])
+        self._down = [topology.pool_operator(m) for m in self.downsample_matrices]
+        self._up = [topology.pool_operator(m) for m in self.upsample_matrices]
+        self._ops_ready = True
+
+    def reset_parameters(self):
+        nn.init.normal_(self.enc_lin.weight, 0, 0.1)
+        nn.init.normal_(self.dec_lin.weight, 0, 0.1)
+
+    def set_param(self, alpha, beta):
+        self.alpha = alpha
+        self.beta = beta
+
+    # ------------------------------------------------------------------ dropout plumbing
+    def _drop_u(self, rows, cols, device):
+        """Uniform randoms for one dropout site, or None in eval mode / p == 0."""
+        if not self.training or self.dropout.p <= 0.0:
+            return None
+        return torch.rand(rows, cols, device=device, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ stages
+    def encoder(self, x):
+        self._prepare()
+        for i in range(self.n_layers):
+            x = F_hip.cheb_conv(x, self.cheb[i].weight, self.cheb[i].bias, self._lap[i], relu=True)
+            x = F_hip.surface_pool(x, self._down[i])
+        x = x.reshape(x.shape[0], self.enc_lin.in_features)
+        return F_hip.linear(x, self.enc_lin.weight, self.enc_lin.bias, relu=True,
+                            drop_u=self._drop_u(x.shape[0], self.num_hidden, x.device), p=self.dropout.p)
+
+    def _latent(self, h, y, m_type):
+        """classifier + latent heads + reparameterisation in one fused kernel."""
+        B = h.shape[0]
+        eps = None
+        if m_type == "train":
+            # drawn on the host default generator, exactly as the reference does (:316)
+            eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(h.device)
+        return F_hip.latent_head(h, y.to(torch.float32), self.classifier_layer.weight, self.classifier_layer.bias,
+                                 self.z_mean.weight, self.z_mean.bias, self.z_log_var.weight, self.z_log_var.bias,
+                                 drop_u=self._drop_u(B, self.num_hidden, h.device), p=self.dropout.p, eps=eps)
+
+    def classifier(self, x):
+        B = x.shape[0]
+        y0 = torch.zeros(B, self.num_class, dtype=torch.float32, device=x.device)
+        return self._latent(x, y0, "test")[0]
+
+    def decoder(self, x):
+        self._prepare()
+        B, dev, p = x.shape[0], x.device, self.dropout.p
+        x = F_hip.linear(x, self.dec_lin.weight, self.dec_lin.bias, relu=True,
+                         drop_u=self._drop_u(B, self.num_hidden, dev), p=p)
+        x = F_hip.linear(x, self.dec_lin_2.weight, self.dec_lin_2.bias, relu=True,
+                         drop_u=self._drop_u(B, self.dec_lin_2.out_features, dev), p=p)
+        x = x.reshape(B, -1, self.filters[-1])
+        for i in range(self.n_layers):
+            x = F_hip.surface_pool(x, self._up[-i - 1])
+            conv = self.cheb_dec[i]
+            x = F_hip.cheb_conv(x, conv.weight, conv.bias, self._lap[self.n_layers - i - 1], relu=True)
+        last = self.cheb_dec[-1]
+        return F_hip.cheb_conv(x, last.weight, last.bias, self._lap_final, relu=False)
+
+    def sample(self, y, z):
+        zy = torch.cat([y.to(z.dtype), z], -1)
+        return self.decoder(zy).reshape(z.shape[0], -1, self.filters[0])
+
+    def reparameterize(self, mu, logvar):
+        eps = torch.normal(mean=0, std=1, size=(mu.shape[0], logvar.shape[1])).to(mu.device)
+        return eps * torch.exp(logvar * 0.5) + mu
+
+    def loss_function(self, x, recon_x, z, mu_z, logvar_z, y, y_hat):
+        return F_hip.vae_loss(recon_x, x, mu_z, logvar_z, y.to(torch.float32), y_hat, LOG_SIGMA)
+
+    # ------------------------------------------------------------------ full step
+    def forward(self, data, x_gt, y, supervise=True, m_type="test"):
+        self.supervise = supervise
+        x, batch_size = data.x, data.num_graphs          # data.edge_index is never used (reference :195)
+        x = x.reshape(batch_size, -1, self.filters[0])
+        h = self.encoder(x)
+        y_hat, x_mean, x_var, z_, z = self._latent(h, y, m_type)
+        x = self.decoder(z).reshape(batch_size, -1, self.filters[0])
+        loss, correct, kld, rec_loss = self.loss_function(x_gt, x, z, x_mean, x_var, y, y_hat)
+        return loss, correct, x, [kld, rec_loss, z_], y_hat

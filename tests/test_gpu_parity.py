@@ -1,0 +1,342 @@
+"""GPU (-m gpu): parity of the HIP path (called through the C ABI via the reference-API
+mirror) against the CPU oracle and the committed golden vectors.
+
+Tolerances (BASELINE.json north_star): index gathers bit-exact; fp32 forward within 1e-4
+absolute (observed ~1e-6); gradients rtol 1e-4 (different but fixed summation order).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFG_5K, ROOT, TINY_CFG, state_dict_from
+
+pytestmark = pytest.mark.gpu
+FWD_ATOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def test_extension_is_loaded_and_gfx950():
+    import meshvae_hip
+    info = meshvae_hip.device_info()
+    assert info["arch"].startswith("gfx950"), info
+    assert info["n_cu"] == 256
+
+
+# ----------------------------------------------------------------------------- row S
+@pytest.mark.parametrize("tag,which,i", [("p_D0", "D", 0), ("p_D1", "D", 1), ("p_U0", "U", 0), ("p_U1", "U", 1)])
+def test_surface_pool_bit_exact(tag, which, i, ops_npz, topotiny_npz):
+    from model import load_topology
+    from nn.pool import SurfacePool
+    dev = _dev()
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), dev)
+    mat = (D if which == "D" else U)[i]
+    x = _t(ops_npz[f"{tag}_x"], dev).requires_grad_(True)
+    y = SurfacePool()(x, mat)
+    assert torch.equal(y.cpu(), _t(ops_npz[f"{tag}_y"]))                  # bit-exact forward
+    y.backward(_t(ops_npz[f"{tag}_gy"], dev))
+    if which == "D":
+        assert torch.equal(x.grad.cpu(), _t(ops_npz[f"{tag}_gx"]))        # unique scatter: exact
+    else:
+        torch.testing.assert_close(x.grad.cpu(), _t(ops_npz[f"{tag}_gx"]), rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="expected size"):
+        SurfacePool()(x[:, :-1], mat)
+
+
+# ----------------------------------------------------------------------------- rows C + Q
+def test_cheb_conv_cases(ops_npz, topotiny_npz):
+    from nn.conv import ChebConv_batch
+    dev = _dev()
+    for case in ops_npz["case_names"]:
+        level, n_x, B, cin, cout, K, has_b = [int(v) for v in ops_npz[f"{case}_meta"]]
+        ei = _t(np.vstack([topotiny_npz[f"A{level}_row"], topotiny_npz[f"A{level}_col"]]).astype(np.int64), dev)
+        ei, nrm = ChebConv_batch.norm(ei, int(topotiny_npz["num_nodes"][level]))
+        assert torch.equal(nrm.cpu(), _t(topotiny_npz[f"A{level}_norm"]))
+        conv = ChebConv_batch(cin, cout, K, bias=bool(has_b)).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(_t(ops_npz[f"{case}_w"]))
+            if has_b:
+                conv.bias.copy_(_t(ops_npz[f"{case}_b"]))
+        x = _t(ops_npz[f"{case}_x"], dev).requires_grad_(True)
+        y = conv(x, ei, nrm)
+        torch.testing.assert_close(y.cpu(), _t(ops_npz[f"{case}_y"]), rtol=0, atol=FWD_ATOL, msg=str(case))
+        err = (y.cpu() - _t(ops_npz[f"{case}_y"])).abs().max().item()
+        assert err < 2e-5, (case, err)
+        y.backward(_t(ops_npz[f"{case}_gy"], dev))
+        torch.testing.assert_close(x.grad.cpu(), _t(ops_npz[f"{case}_gx"]), rtol=1e-4, atol=1e-4, msg=str(case))
+        torch.testing.assert_close(conv.weight.grad.cpu(), _t(ops_npz[f"{case}_gw"]), rtol=1e-4, atol=1e-4, msg=str(case))
+        if has_b:
+            torch.testing.assert_close(conv.bias.grad.cpu(), _t(ops_npz[f"{case}_gb"]), rtol=1e-4, atol=1e-4)
+
+
+def test_cheb_conv_fused_relu_and_first_layer(ops_npz, topotiny_npz):
+    from nn.conv import ChebConv_batch
+    dev = _dev()
+    case = "c_16_16_k6"
+    ei = _t(np.vstack([topotiny_npz["A0_row"], topotiny_npz["A0_col"]]).astype(np.int64), dev)
+    ei, nrm = ChebConv_batch.norm(ei, 162)
+    conv = ChebConv_batch(16, 16, 6).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(_t(ops_npz[f"{case}_w"]))
+        conv.bias.copy_(_t(ops_npz[f"{case}_b"]))
+    x = _t(ops_npz[f"{case}_x"], dev)                        # no grad on x: dx path skipped
+    y = conv(x, ei, nrm, relu=True)
+    torch.testing.assert_close(y.cpu(), _t(ops_npz[f"{case}_y"]).clamp_min(0), rtol=0, atol=FWD_ATOL)
+    gy = _t(ops_npz[f"{case}_gy"], dev)
+    y.backward(gy)
+    # oracle for the fused form
+    from oracle import cheb_oracle as O
+    xo = _t(ops_npz[f"{case}_x"])
+    wo = _t(ops_npz[f"{case}_w"]).requires_grad_(True)
+    bo = _t(ops_npz[f"{case}_b"]).requires_grad_(True)
+    eio, nrmo = O.cheb_norm(ei.cpu(), 162)
+    torch.relu(O.cheb_conv(xo, eio, nrmo, wo, bo)).backward(gy.cpu())
+    torch.testing.assert_close(conv.weight.grad.cpu(), wo.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(conv.bias.grad.cpu(), bo.grad, rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- dense head + loss
+def test_linear_latent_loss_against_oracle():
+    from meshvae_hip import functional as Fh
+    from oracle import cheb_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, H, C, Z = 5, 70, 2, 16
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    # linear + relu (+ dropout mask injected through the uniforms)
+    x, W, b = rnd(B, 37), rnd(H, 37) * 0.3, rnd(H) * 0.3
+    u = torch.rand(B, H, generator=g)
+    p = 0.2
+    xo, Wo, bo = (t.clone().requires_grad_(True) for t in (x, W, b))
+    yo = torch.relu(torch.nn.functional.linear(xo, Wo, bo)) * (u >= p) / (1 - p)
+    xd, Wd, bd = (t.clone().to(dev).requires_grad_(True) for t in (x, W, b))
+    yd = Fh.linear(xd, Wd, bd, relu=True, drop_u=u.to(dev), p=p)
+    torch.testing.assert_close(yd.cpu(), yo, rtol=1e-5, atol=1e-5)
+    gy = rnd(B, H)
+    yo.backward(gy)
+    yd.backward(gy.to(dev))
+    for a, r in ((xd, xo), (Wd, Wo), (bd, bo)):
+        torch.testing.assert_close(a.grad.cpu(), r.grad, rtol=1e-4, atol=1e-5)
+
+    # latent head, train mode with eps and the classifier's dropout
+    h = torch.relu(rnd(B, H))
+    y = torch.nn.functional.one_hot(torch.arange(B) % C, C)
+    P = {k: (rnd(*s) * 0.2) for k, s in dict(Wc=(C, H), bc=(C,), Wm=(Z, H + C), bm=(Z,), Wv=(Z, H + C), bv=(Z,)).items()}
+    eps, u2 = rnd(B, Z), torch.rand(B, H, generator=g)
+    ho = h.clone().requires_grad_(True)
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    hd = ho * (u2 >= p) / (1 - p)
+    yh_o = torch.softmax(torch.nn.functional.linear(hd, Po["Wc"], Po["bc"]), 1)
+    hy = torch.cat([y, ho], -1)
+    mu_o = torch.nn.functional.linear(hy, Po["Wm"], Po["bm"])
+    lv_o = torch.nn.functional.linear(hy, Po["Wv"], Po["bv"])
+    z_o = eps * torch.exp(lv_o * 0.5) + mu_o
+    hdv = h.clone().to(dev).requires_grad_(True)
+    Pd = {k: v.clone().to(dev).requires_grad_(True) for k, v in P.items()}
+    yh, mu, lv, z, zy = Fh.latent_head(hdv, y.float().to(dev), Pd["Wc"], Pd["bc"], Pd["Wm"], Pd["bm"], Pd["Wv"],
+                                       Pd["bv"], drop_u=u2.to(dev), p=p, eps=eps.to(dev))
+    for a, r in ((yh, yh_o), (mu, mu_o), (lv, lv_o), (z, z_o)):
+        torch.testing.assert_close(a.cpu(), r, rtol=1e-5, atol=1e-5)
+    assert torch.equal(zy[:, :C].cpu(), y.float()) and torch.equal(zy[:, C:], z)
+
+    # loss on top (fp32 and fp64 ground truth), gradients flow back through the head
+    NV = 33
+    recon, gt = rnd(B, 11, 3), rnd(B, 11, 3)
+    for dtype in (torch.float32, torch.float64):
+        for t in list(Po.values()) + [ho, hdv] + list(Pd.values()):
+            t.grad = None
+        ro = recon.clone().requires_grad_(True)
+        ls = O.softclip(torch.Tensor([1]), -6)
+        k_o = O.kld(mu_o, lv_o)
+        rec_o = O.gaussian_nll(ro, ls, gt.to(dtype)).sum(-1).sum(-1)
+        loss_o = (k_o + rec_o - 2 * (yh_o * y).sum(-1).log()).mean() + 0.1 * (z_o ** 2).sum()
+        rd = recon.clone().to(dev).requires_grad_(True)
+        loss, correct, kld, rec = Fh.vae_loss(rd, gt.to(dtype).to(dev), mu, lv, y.float().to(dev), yh, float(ls))
+        assert loss.dtype == dtype and rec.dtype == dtype and kld.dtype == torch.float32
+        total = loss + 0.1 * (zy[:, C:] ** 2).sum()
+        torch.testing.assert_close(total.cpu(), loss_o, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(rec.cpu(), rec_o.detach(), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(kld.cpu(), k_o.detach(), rtol=1e-5, atol=1e-5)
+        assert int(correct) == int((yh_o.argmax(1) == y.argmax(1)).sum())
+        loss_o.backward(retain_graph=True)
+        total.backward(retain_graph=True)
+        torch.testing.assert_close(rd.grad.cpu(), ro.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(hdv.grad.cpu(), ho.grad, rtol=1e-4, atol=1e-5)
+        for k in P:
+            torch.testing.assert_close(Pd[k].grad.cpu(), Po[k].grad, rtol=1e-4, atol=1e-5, msg=k)
+
+
+# ----------------------------------------------------------------------------- full model vs golden
+def _build(which, dev, dropout=None):
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    cfg, topo = (TINY_CFG, "topology_tiny.npz") if which == "tiny" else (CFG_5K, "topology_5k.npz")
+    if dropout is not None:
+        cfg = dict(cfg, dropout=dropout)
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", topo), dev)
+    torch.manual_seed(666)
+    return cheb_VAE(3, cfg, D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
+
+
+class _Data:
+    def __init__(self, x):
+        self.x, self.num_graphs, self.edge_index = x.reshape(-1, x.shape[-1]), x.shape[0], None
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_full_model_eval_matches_reference(which, model_tiny_npz, model_5k_npz):
+    npz = model_tiny_npz if which == "tiny" else model_5k_npz
+    dev = _dev()
+    net = _build(which, dev)
+    assert all(torch.equal(v.cpu(), state_dict_from(npz)[k]) for k, v in net.state_dict().items())
+    net.eval()
+    x, y = _t(npz["x"], dev), _t(npz["y"], dev)
+    with torch.no_grad():
+        h = net.encoder(x)
+        loss, correct, recon, (kld, rec, z_), y_hat = net(_Data(x), x.clone(), y, m_type="test")
+        loss64, _, _, (_, rec64, _), _ = net(_Data(x), x.double(), y, m_type="test")
+        oppo = net.sample(1 - y, z_)
+        y_hat2 = net.classifier(h)
+    A = FWD_ATOL
+    torch.testing.assert_close(h.cpu(), _t(npz["eval/h"]), rtol=0, atol=A)
+    torch.testing.assert_close(y_hat.cpu(), _t(npz["eval/y_hat"]), rtol=0, atol=A)
+    torch.testing.assert_close(y_hat2.cpu(), _t(npz["eval/y_hat"]), rtol=0, atol=A)
+    torch.testing.assert_close(z_.cpu(), _t(npz["eval/mu"]), rtol=0, atol=A)
+    torch.testing.assert_close(kld.cpu(), _t(npz["eval/kld"]), rtol=0, atol=A)
+    torch.testing.assert_close(recon.cpu(), _t(npz["eval/recon"]), rtol=0, atol=A)   # recon L2 vs reference
+    torch.testing.assert_close(oppo.cpu(), _t(npz["eval/oppo_recon"]), rtol=0, atol=A)
+    torch.testing.assert_close(rec.cpu(), _t(npz["eval/rec"]), rtol=2e-6, atol=1e-2)
+    torch.testing.assert_close(loss.cpu(), _t(npz["eval/loss"]), rtol=2e-6, atol=1e-2)
+    assert rec64.dtype == torch.float64 and loss64.dtype == torch.float64
+    torch.testing.assert_close(rec64.cpu(), _t(npz["eval/rec64"]), rtol=1e-7, atol=1e-3)
+    torch.testing.assert_close(loss64.cpu(), _t(npz["eval/loss64"]), rtol=1e-7, atol=1e-3)
+    assert int(correct) == int(npz["eval/correct"]) and correct.dtype == torch.int64
+    l2 = (recon.cpu() - _t(npz["eval/recon"])).pow(2).sum().sqrt().item()
+    print(f"[{which}] recon L2 vs reference = {l2:.3e}, max|d| = {(recon.cpu() - _t(npz['eval/recon'])).abs().max():.3e}")
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_full_model_train_step_matches_reference(which, model_tiny_npz, model_5k_npz):
+    npz = model_tiny_npz if which == "tiny" else model_5k_npz
+    dev = _dev()
+    net = _build(which, dev, dropout=0.0)
+    net.train()
+    x, y = _t(npz["x"], dev), _t(npz["y"], dev)
+    torch.manual_seed(123)                                   # host-side eps (cheb_VAE.py:316)
+    loss, correct, recon, (kld, rec, z_), y_hat = net(_Data(x), x.clone(), y, m_type="train")
+    loss.backward()
+    torch.testing.assert_close(z_.detach().cpu(), _t(npz["train/z"]), rtol=0, atol=FWD_ATOL)
+    torch.testing.assert_close(loss.detach().cpu(), _t(npz["train/loss"]), rtol=2e-6, atol=1e-2)
+    torch.testing.assert_close(recon.detach()[:, :64].cpu(), _t(npz["train/recon_slice"]), rtol=0, atol=FWD_ATOL)
+    names = [str(n) for n in npz["train/grad_names"]]
+    got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(names)
+    assert net.dec_lin_1.weight.grad is None
+    worst = 0.0
+    for k in names:
+        want = _t(npz[f"train/grad/{k}"])
+        scale = float(npz[f"train/gnorm/{k}"]) / max(want.numel() ** 0.5, 1.0)
+        torch.testing.assert_close(got[k].cpu(), want, rtol=1e-3, atol=1e-4 * max(scale, 1e-3), msg=k)
+        rel = (got[k].cpu() - want).norm().item() / max(float(npz[f"train/gnorm/{k}"]), 1e-12)
+        worst = max(worst, rel)
+        assert rel < 1e-4, (k, rel)
+    print(f"[{which}] worst relative gradient error = {worst:.3e}")
+
+
+def test_train_mode_dropout_statistics_and_determinism():
+    dev = _dev()
+    net = _build("tiny", dev)
+    net.train()
+    x = torch.randn(64, net.num_nodes[0], 3, device=dev)
+    h = net.encoder(x)
+    frac = (h == 0).float().mean().item()
+    net.eval()
+    h_eval = net.encoder(x)
+    base = (h_eval == 0).float().mean().item()
+    expect = base + (1 - base) * 0.2
+    assert abs(frac - expect) < 0.03, (frac, expect)
+    kept = (h != 0) & (h_eval != 0)
+    torch.testing.assert_close(h[kept], h_eval[kept] / 0.8, rtol=1e-6, atol=1e-6)
+    assert torch.equal(net.encoder(x), h_eval)               # eval path is run-to-run bit-stable
+
+
+# ----------------------------------------------------------------------------- full-size properties (B = 64)
+def test_full_size_properties_b64(topo5k_npz):
+    from nn.conv import ChebConv_batch
+    from nn.pool import SurfacePool
+    dev = _dev()
+    net = _build("5k", dev)
+    net.eval()
+    net._prepare()
+    B = 64
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x16 = torch.randn(B, 4998, 16, generator=g).to(dev)
+    # D: pure index gather, bit exact
+    y = SurfacePool()(x16, net.downsample_matrices[0])
+    assert torch.equal(y, x16[:, _t(topo5k_npz["D0_col"].astype(np.int64), dev)])
+    # U: rows sum the 3 taps in COO order -> equals the oracle on a slice, bit exact
+    from oracle import cheb_oracle as O
+    topo = O.Topology(topo5k_npz)
+    xs = torch.randn(2, 1250, 16, generator=g)
+    assert torch.equal(SurfacePool()(xs.to(dev), net.upsample_matrices[0]).cpu(), O.surface_pool(xs, *topo.U[0]))
+    # conv: linearity in x, zero input -> bias, and agreement with the oracle on 2 meshes of the batch
+    conv = net.cheb_dec[3]
+    ei, nrm = net.A_edge_index[0], net.A_norm[0]
+    with torch.no_grad():
+        a, b2 = conv(x16, ei, nrm), conv(2 * x16, ei, nrm)
+        z0 = conv(torch.zeros_like(x16[:1]), ei, nrm)
+        torch.testing.assert_close(b2 - conv.bias, 2 * (a - conv.bias), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(z0, conv.bias.expand_as(z0), rtol=0, atol=0)
+        ref = O.cheb_conv(x16[:2].cpu(), ei.cpu(), nrm.cpu(), conv.weight.cpu(), conv.bias.cpu())
+        torch.testing.assert_close(a[:2].cpu(), ref, rtol=0, atol=FWD_ATOL)
+        assert torch.equal(conv(x16, ei, nrm), a)            # deterministic
+    # the quirk at full size: rows >= 20 are x (W0 - W2 + W4)
+    last = net.cheb_dec[4]
+    with torch.no_grad():
+        out = last(x16, net.A_edge_index[-1], net.A_norm[-1])
+        closed = x16[:, 20:] @ (last.weight[0] - last.weight[2] + last.weight[4])
+    torch.testing.assert_close(out[:, 20:], closed, rtol=1e-4, atol=1e-4)
+    # gradients are bitwise reproducible (no atomics)
+    xin = torch.randn(B, 4998, 3, generator=g).to(dev)
+    grads = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        loss = net(_Data(xin), xin.clone(), torch.nn.functional.one_hot(torch.arange(B, device=dev) % 2, 2), m_type="test")[0]
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+
+
+def test_edge_cases():
+    from nn.conv import ChebConv_batch
+    dev = _dev()
+    # a graph with isolated vertices and a self loop: deg^-1/2 = inf -> 0 (nn/conv.py:552-553)
+    ei = torch.tensor([[0, 1, 2, 2], [1, 0, 2, 0]], device=dev)
+    ei2, nrm = ChebConv_batch.norm(ei, 5)
+    assert ei2.shape[1] == 3 and torch.isfinite(nrm).all()
+    conv = ChebConv_batch(3, 4, 3).to(dev)
+    x = torch.randn(2, 5, 3, device=dev, requires_grad=True)
+    y = conv(x, ei2, nrm)
+    from oracle import cheb_oracle as O
+    ref = O.cheb_conv(x.detach().cpu(), ei2.cpu(), nrm.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu())
+    torch.testing.assert_close(y.detach().cpu(), ref, rtol=0, atol=1e-5)
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all()
+    # empty edge list and batch of one
+    e0 = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    y0 = conv(x[:1], e0, torch.zeros(0, device=dev))
+    torch.testing.assert_close(y0, x[:1] @ (conv.weight[0] - conv.weight[2]) + conv.bias, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        conv(x, ei2.float(), nrm)
+    with pytest.raises(TypeError):
+        conv(x.double(), ei2, nrm)

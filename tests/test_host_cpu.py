@@ -1,0 +1,152 @@
+"""CPU (-m "not gpu"): C-ABI library loads and exports every declared symbol, host-side
+topology preprocessing, reference-API surface, init-order parity, loud failure without GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFG_5K, ROOT, TINY_CFG, state_dict_from
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "meshvae_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    import meshvae_hip
+    syms = _header_symbols()
+    assert len(syms) >= 17
+    lib = meshvae_hip.lib()                      # loads the .so (no GPU needed, no compute)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/meshvae_hip.h but not exported"
+        assert s in meshvae_hip.SIGNATURES, f"{s} has no ctypes signature"
+    assert sorted(meshvae_hip.SIGNATURES) == syms
+    assert lib.mvh_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    """Host-side checks fire before any kernel launch."""
+    import ctypes
+    import meshvae_hip
+    lib = meshvae_hip.lib()
+    rc = lib.mvh_spmm(None, None, None, None, None, None, 1.0, 0.0, 1, 4, 0)
+    assert rc == 1 and b"null CSR" in lib.mvh_last_error()
+    csr = meshvae_hip.CsrStruct(4, 4, 0, 8, None, None)   # fake non-null rowptr, never dereferenced on host
+    rc = lib.mvh_cheb_conv_fwd(None, ctypes.byref(csr), 8, 8, None, 8, None, 1, 5, 3, 3, 2, 0, None, 0)
+    assert rc == 1 and b"vertices" in lib.mvh_last_error()
+    rc = lib.mvh_cheb_conv_fwd(None, ctypes.byref(csr), 8, 8, None, 8, None, 1, 4, 3, 3, 0, 0, None, 0)
+    assert rc == 1 and b"K must be > 0" in lib.mvh_last_error()
+    with pytest.raises(meshvae_hip.MeshVaeHipError):
+        meshvae_hip.check(rc)
+
+
+def _dense(op_csr):
+    m = np.zeros((op_csr.n_rows, op_csr.n_cols), dtype=np.float64)
+    rp, col, val = op_csr.rowptr.numpy(), op_csr.col.numpy(), op_csr.val.numpy()
+    for r in range(op_csr.n_rows):
+        for e in range(rp[r], rp[r + 1]):
+            m[r, col[e]] += val[e]
+    return m
+
+
+def test_csr_conversion_keeps_reference_edge_order(topotiny_npz):
+    from meshvae_hip.topology import Operator
+    npz = topotiny_npz
+    row, col, val = (torch.from_numpy(npz[f"U0_{k}"].astype(np.int64 if k != "val" else np.float32)) for k in ("row", "col", "val"))
+    n_out, n_in = (int(v) for v in npz["U0_shape"])
+    op = Operator(row, col, val, n_out, n_in, "cpu")
+    dense = np.zeros((n_out, n_in))
+    np.add.at(dense, (row.numpy(), col.numpy()), val.numpy().astype(np.float64))
+    np.testing.assert_allclose(_dense(op.fwd), dense, rtol=0, atol=0)
+    np.testing.assert_allclose(_dense(op.bwd), dense.T, rtol=0, atol=0)
+    # stable: entries of one output row appear in COO order
+    rp = op.fwd.rowptr.numpy()
+    for r in range(n_out):
+        want = col.numpy()[row.numpy() == r]
+        assert np.array_equal(op.fwd.col.numpy()[rp[r]:rp[r + 1]], want)
+    assert op.fwd.max_row_nnz == 3
+    with pytest.raises(ValueError):
+        Operator(row, col, val, n_out - 1, n_in, "cpu")
+
+
+def test_laplacian_quirk_has_empty_rows(topotiny_npz):
+    from meshvae_hip import topology
+    from nn.conv import ChebConv_batch
+    ei = torch.from_numpy(np.vstack([topotiny_npz["A2_row"], topotiny_npz["A2_col"]]).astype(np.int64))
+    ei, nrm = ChebConv_batch.norm(ei, 11)
+    assert torch.equal(nrm, torch.from_numpy(topotiny_npz["A2_norm"]))
+    op = topology.laplacian(ei, nrm, 162)            # coarsest edges on the finest vertex set
+    rp = op.fwd.rowptr.numpy()
+    assert op.fwd.n_rows == 162 and rp[11] == rp[-1] == ei.shape[1]
+    assert topology.laplacian(ei, nrm, 162) is op    # cached
+    with pytest.raises(ValueError):
+        topology.laplacian(ei.float(), nrm, 162)
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_model_init_is_bit_identical_to_reference(which, model_tiny_npz, model_5k_npz):
+    from model import load_topology
+    from models.cheb_VAE import LOG_SIGMA, cheb_VAE
+    npz, cfg, topo = ((model_tiny_npz, TINY_CFG, "topology_tiny.npz") if which == "tiny"
+                      else (model_5k_npz, CFG_5K, "topology_5k.npz"))
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", topo), "cpu")
+    torch.manual_seed(666)
+    net = cheb_VAE(3, cfg, D, U, A, nn_, model="optimal_sigma_VAE")
+    want = state_dict_from(npz)
+    got = net.state_dict()
+    assert list(got.keys()) == list(want.keys())           # names AND order (31 tensors at 5k)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert abs(LOG_SIGMA - 1.0009117) < 1e-6
+    net.load_state_dict(want)                               # reference checkpoints load unchanged
+    for attr in ("encoder", "classifier", "decoder", "sample", "reparameterize", "loss_function",
+                 "set_param", "z_mean", "z_log_var", "A_edge_index", "A_norm"):
+        assert hasattr(net, attr)
+
+
+def test_no_cpu_fallback():
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    from nn.conv import ChebConv_batch
+    from nn.pool import SurfacePool
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), "cpu")
+    net = cheb_VAE(3, TINY_CFG, D, U, A, nn_)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.encoder(torch.zeros(2, nn_[0], 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SurfacePool()(torch.zeros(2, nn_[0], 4), D[0])
+    conv = ChebConv_batch(3, 4, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(torch.zeros(2, nn_[0], 3), net.A_edge_index[0], net.A_norm[0])
+    with pytest.raises(AssertionError):
+        ChebConv_batch(3, 4, 0)                             # K > 0 (nn/conv.py:445)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mesh-vae_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(d, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(d, f)
+
+
+def test_get_model_side_effects(tmp_path, capsys):
+    from model import get_model, scipy_to_torch_sparse
+    import scipy.sparse as sp
+    cfg = dict(TINY_CFG, topology=os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"),
+               checkpoint_dir=str(tmp_path), type="cheb_VAE", model="optimal_sigma_VAE")
+    net = get_model(cfg, "cpu")
+    out = capsys.readouterr().out
+    assert "Using model: cheb_VAE" in out and "cheb.0.weight : torch.Size([6, 3, 8])" in out
+    sd = torch.load(os.path.join(str(tmp_path), "initial_weight.pt"))
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    m = sp.coo_matrix(([1.0, 2.0, 3.0], ([2, 0, 1], [1, 1, 0])), shape=(3, 2))
+    t = scipy_to_torch_sparse(m)
+    assert t._indices().tolist() == [[2, 0, 1], [1, 1, 0]] and t._values().tolist() == [1.0, 2.0, 3.0]
+    with pytest.raises(NotImplementedError):
+        get_model(dict(cfg, topology=None), "cpu")
