@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: meshes/s, forward+backward(+all-reduce+Adam), 5k-vertex ChebConv VAE.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one train step of models.cheb_VAE on a synthetic batch of 64 meshes per GPU
+(BASELINE.json configs[1]: default.cfg architecture on the 4998-vertex template, K=6, fp32,
+dropout 0.2 on, x ~ N(0,1), x_gt = x as fp64 like main.py): forward, backward, one flat RCCL
+all-reduce of the gradients when N > 1, fused Adam.  Inputs are resident in HBM before the
+timed region.  Weak scaling: 64 meshes per rank.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "mesh-vae_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TOPOLOGY = os.path.join(ROOT, "tests", "golden", "topology_5k.npz")
+CFG = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_order": [6, 6, 6, 6, 6],
+       "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
+# module-boundary HBM bytes per mesh, fp32, forward + backward
+ALGO_BYTES_PER_MESH = 7.80e6
+ALGO_FLOP_PER_MESH = 139.4e6
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def build_model(dev):
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    D, U, A, nn_ = load_topology(TOPOLOGY, dev)
+    torch.manual_seed(666)
+    return cheb_VAE(3, CFG, D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
+
+
+def time_kernel(fn, iters=30, warm=5):
+    """Average device time (ms) of `fn` measured with HIP events on the launching stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(net, B, dev):
+    """Per-kernel algorithmic bytes / measured duration for the level-0 kernels of one step.
+    Algorithmic bytes = each operand of the launch read or written exactly once."""
+    import ctypes
+    from meshvae_hip import check, lib
+    from meshvae_hip.functional import workspace
+    L = lib()
+    net._prepare()
+    lap = net._lap[0]
+    N, C, K, Cout = net.num_nodes[0], 16, 6, 16
+    st = torch.cuda.current_stream(dev).cuda_stream
+    plane = B * N * C
+    x = torch.randn(B, N, C, device=dev)
+    tx = torch.randn(K - 1, B, N, C, device=dev)
+    out = torch.randn(B, N, Cout, device=dev)
+    dout = torch.randn(B, N, Cout, device=dev)
+    W = torch.randn(K, C, Cout, device=dev) * 0.1
+    bias = torch.zeros(Cout, device=dev)
+    dW, db, dx = torch.empty_like(W), torch.empty_like(bias), torch.empty_like(x)
+    ws_b = L.mvh_cheb_conv_bwd_ws_bytes(B, N, C, Cout, K)
+    ws = workspace(ws_b, dev)
+    res = {}
+
+    def spmm():
+        check(L.mvh_spmm(st, lap.fwd.ref, tx[0].data_ptr(), tx[1].data_ptr(), None, x.data_ptr(), 2.0, -1.0, B, C, 0))
+    ms = time_kernel(spmm)
+    res["k_spmm<4,false> (L0, 16ch recurrence step)"] = dict(ms=ms, bytes=3 * plane * 4 + lap.fwd.nnz * 8, launches_per_step=30)
+
+    def fwd():
+        check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                  tx.data_ptr(), B, N, C, Cout, K, 1, None, 0))
+    ms_f = time_kernel(fwd)
+    res["mvh_cheb_conv_fwd (L0 16->16, all launches)"] = dict(ms=ms_f, bytes=2 * plane * 4, launches_per_step=1)
+
+    def bwd():
+        check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                  dout.data_ptr(), tx.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                  B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
+    ms_b = time_kernel(bwd)
+    res["mvh_cheb_conv_bwd (L0 16->16, all launches)"] = dict(ms=ms_b, bytes=4 * plane * 4, launches_per_step=1)
+    return res
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup quota) -- the GPU box exposes
+    256 hardware threads but caps the container at 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(B, steps):
+    """The CPU oracle (a port of the reference dataflow) timed on this box's host cores."""
+    from oracle import cheb_oracle as O
+    n_threads = host_cores()
+    torch.set_num_threads(n_threads)
+    topo = O.Topology(np.load(TOPOLOGY))
+    torch.manual_seed(666)
+    sd = O.init_state_dict(CFG, topo)
+    net = O.OracleVAE(CFG, topo, sd, requires_grad=True)
+    net.training = True
+    x = torch.randn(B, 4998, 3, generator=torch.Generator().manual_seed(0))
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
+
+    def step():
+        for p in net.p.values():
+            p.grad = None
+        net.forward(x, x.double(), y, "train")[0].backward()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "meshes/s", "cores": n_threads, "kind": "port",
+            "sample": f"{steps} train steps (fwd+bwd) of B={B} on the same 5k model after 1 warm-up step, "
+                      f"torch {torch.__version__} CPU, {n_threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from meshvae_hip.engine import TrainStep
+    net = build_model(dev)
+    net.train()
+    B = args.batch
+    step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=not args.no_graph, m_type="train")
+    g = torch.Generator().manual_seed(rank)
+    x = torch.randn(B, 4998, 3, generator=g)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
+    step.x.copy_(x)
+    step.x_gt = x.double().to(dev)                   # fp64 ground truth, as main.py:69-70 hands it over
+    step.y.copy_(y)
+    if step.use_graph:
+        step.capture()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(step.out[0])
+    assert np.isfinite(loss), "non-finite loss in the benchmark step"
+
+    if rank == 0:
+        meshes_per_s = world * B * args.steps / dt
+        out = {
+            "metric": "meshes/sec fwd+bwd, 5k-vertex ChebConv VAE",
+            "value": meshes_per_s, "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: default.cfg 5k-vertex K=6 ChebConv VAE train step "
+                                   "(fwd+bwd+grad all-reduce+Adam), 64 meshes/GPU, fp32, dropout 0.2",
+                       "global_batch": world * B, "per_gpu_batch": B, "vertices": 4998,
+                       "parallelism": f"dp{world}", "hipgraph": bool(step.use_graph)},
+            "step_roofline": {"bound": "hbm", "achieved": meshes_per_s / world * ALGO_BYTES_PER_MESH / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": meshes_per_s / world * ALGO_BYTES_PER_MESH / 1e9 / HBM_PEAK_GBS,
+                              "note": "whole step per GPU: meshes/s x 7.80 MB/mesh (SURVEY 8(d))"},
+            "final_loss": loss,
+        }
+        if not args.no_kernel_roofline:
+            ks = kernel_rooflines(net, B, dev)
+            name = max((k for k in ks if k.startswith("k_")), key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
+            d = ks[name]
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_us": d["ms"] * 1e3, "algorithmic_bytes_per_launch": d["bytes"]}
+            out["kernels"] = {k: {"avg_ms": v["ms"], "algo_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, 2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

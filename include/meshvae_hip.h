@@ -148,6 +148,14 @@ int mvh_vae_loss_bwd(mvh_stream_t stream, const float* recon, const void* x_gt, 
                      float log_sigma, const void* d_loss, float* d_recon, float* d_mu,
                      float* d_logvar, float* d_yhat, int32_t B, int32_t NV, int32_t C, int32_t Z);
 
+/* ---- train-loop optimizer (reference main.py:251, :80-81: torch.optim.Adam with coupled L2
+ * weight_decay) over the flat parameter buffer.  step_count is a device int32 incremented by
+ * the call (so the step is hipGraph-replayable); grad is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). */
+int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
+                  float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float grad_scale, int32_t* step_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,8 +111,12 @@ class cheb_VAE(torch.nn.Module):
         B = h.shape[0]
         eps = None
         if m_type == "train":
-            # drawn on the host default generator, exactly as the reference does (:316)
-            eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(h.device)
+            provider = getattr(self, "_eps_provider", None)
+            if provider is not None:       # engine.TrainStep: static device buffer refilled from the host RNG
+                eps = provider(B, self.z, h.device)
+            else:
+                # drawn on the host default generator, exactly as the reference does (:316)
+                eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(h.device)
         return F_hip.latent_head(h, y.to(torch.float32), self.classifier_layer.weight, self.classifier_layer.bias,
                                  self.z_mean.weight, self.z_mean.bias, self.z_log_var.weight, self.z_log_var.bias,
                                  drop_u=self._drop_u(B, self.num_hidden, h.device), p=self.dropout.p, eps=eps)
