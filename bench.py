@@ -86,13 +86,13 @@ def kernel_rooflines(net, B, dev):
 
     def fwd():
         check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                  tx.data_ptr(), B, N, C, Cout, K, 1, None, 0))
+                                  None, B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
     ms_f = time_kernel(fwd)
     res["mvh_cheb_conv_fwd (L0 16->16, all launches)"] = dict(ms=ms_f, bytes=2 * plane * 4, launches_per_step=1)
 
     def bwd():
         check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                  dout.data_ptr(), tx.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                  dout.data_ptr(), None, dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
                                   B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
     ms_b = time_kernel(bwd)
     res["mvh_cheb_conv_bwd (L0 16->16, all launches)"] = dict(ms=ms_b, bytes=4 * plane * 4, launches_per_step=1)

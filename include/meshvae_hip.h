@@ -48,7 +48,23 @@ typedef struct mvh_csr {
   const int32_t* rowptr; /* [n_rows+1] device */
   const int32_t* col;    /* [nnz]      device */
   const float* val;      /* [nnz]      device */
+  /* Optional compact form for the LDS-resident kernels (NULL / 0 = not available, the
+   * general kernels are used).  rowinfo[r] = (rowptr[r] << 8) | row_length.  ell is the
+   * column list in padded ELL form, two uint16 columns per word, pair-slot major:
+   * ell[p * n_rows + r] = col(r, 2p) | col(r, 2p+1) << 16 for p < ell_pairs, with the
+   * out-of-row slots set to n_cols (an all-zero dummy row the kernels append in LDS). */
+  const uint32_t* rowinfo; /* [n_rows] device */
+  const uint32_t* ell;     /* [ell_pairs * n_rows] device */
+  int32_t ell_pairs;       /* ceil(max_row_nnz / 2) */
+  int32_t max_row_nnz;
+  int32_t flags;           /* MVH_CSR_* */
 } mvh_csr_t;
+
+/* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh
+ * Laplacian of ChebConv_batch.norm (nn/conv.py:541-555) on unit edge weights. */
+#define MVH_CSR_NORMALIZED_LAPLACIAN 1
+/* the operator equals its transpose (same pattern, same values) */
+#define MVH_CSR_SYMMETRIC 2
 
 int mvh_version(void);
 const char* mvh_last_error(void);

@@ -280,7 +280,7 @@ using namespace mvh;
 
 extern "C" size_t mvh_cheb_conv_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
   (void)Cout;
-  return align_up((size_t)(K > 1 ? K - 1 : 0) * B * N * Cin * sizeof(float), 256) + 256;
+  return kLdsWpackBytes + align_up((size_t)(K > 1 ? K - 1 : 0) * B * N * Cin * sizeof(float), 256) + 256;
 }
 
 static int conv_args_ok(const mvh_csr_t* lap, int B, int N, int Cin, int Cout, int K) {
@@ -301,10 +301,16 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   if ((long long)B * N == 0) return MVH_OK;
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
+  if (!tx_saved) {  // fused path: one launch, no T_k stack
+    bool handled = false;
+    float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
+    if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled)) return rc;
+    if (handled) return MVH_OK;
+  }
   float* tx = tx_saved;
   if (!tx && K > 1) {
     MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");
-    tx = (float*)ws;
+    tx = (float*)((char*)ws + kLdsWpackBytes);
   }
   if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
   return launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act);
@@ -315,7 +321,7 @@ extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, 
   size_t tx = align_up((size_t)(K > 1 ? K - 1 : 0) * rows * Cin * sizeof(float), 256);
   size_t g = align_up((size_t)K * rows * Cin * sizeof(float), 256);
   size_t part = align_up((size_t)dw_grid((long long)rows) * ((size_t)K * Cin + 1) * Cout * sizeof(float), 256);
-  return tx + g + part + 256;
+  return kLdsWpackBytes + tx + g + part + 256;
 }
 
 extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
@@ -332,6 +338,8 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
   char* p = (char*)ws;
+  float* wpack = (float*)p;
+  p += kLdsWpackBytes;
   float* tx_ws = (float*)p;
   p += align_up((size_t)(K > 1 ? K - 1 : 0) * plane * sizeof(float), 256);
   float* G = (float*)p;
@@ -349,6 +357,12 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   }
   if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
   if (!dx) return MVH_OK;
+  {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
+    bool handled = false;
+    if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
+                              Cout, K, act, true, wpack, &handled)) return rc;
+    if (handled) return MVH_OK;
+  }
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
   float* g0 = (K == 1) ? dx : G;
   if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act)) return rc;

@@ -1,0 +1,344 @@
+// LDS-resident ChebConv: the whole K-order recurrence of ONE mesh stays on one CU.
+//
+//   out = act( sum_k T_k(L) (In W_k) + bias )       In = x (forward)  or  dpre (backward dX,
+//                                                    with W_k^T; L is symmetric)
+// is evaluated by Clenshaw's recurrence on the OUTPUT side,
+//   b_k = In W_k + 2 L b_{k+1} - b_{k+2},   out = In W_0 + L b_1 - b_2,
+// so every output channel is independent and a workgroup owns (mesh, slab of 4 output channels):
+//   * LDS   : b_{k+1} of the slab for every vertex as one float4 (80 KB at N=4998) and the
+//             neighbour lists in padded ELL form, vertex-major, two uint16 per word (80 KB):
+//             together exactly the CU's 160 KB at the 5k template;
+//   * VGPRs : the input rows In[v][0:CQ] of the thread's own VPT vertices (512 threads x 10
+//             vertices at N=4998; read from HBM once, 16 B/lane coalesced) and b_{k+2}[own];
+//   * SGPRs : the weight slab (wave-uniform scalar loads);
+//   * per order: In W_k as v_fma with SGPR weights, one ds_read_b128 of 8 neighbour ids and one
+//             unweighted ds_read_b128 gather per neighbour, two barriers.  No global traffic
+//             between orders.
+// L = -D^-1/2 A D^-1/2 is applied in scaled variables u = D^-1/2 b so the edge list needs no
+// values:  u_k = s (In W_k) - (2/deg) sum_{j in N(i)} u_{k+1}[j] - u_{k+2},  s = deg^-1/2
+// (s = 1 and no gather for isolated vertices, which covers the final-layer quirk,
+// cheb_VAE.py:288).  Slots past N carry zeros (s = 0) and own a zero row, so the padded ELL
+// entries (index N) gather zeros and no branch on validity exists before the final store.
+// Replaces 5 propagate launches + 1 contraction of the stack pipeline with one launch whose
+// HBM traffic is the module boundary: read In once (per slab, L2-shared), write out once.
+#include "common.hpp"
+
+namespace mvh {
+
+struct LdsConvArgs {
+  const float* in;
+  const float* mask;
+  const float* W;
+  const float* bias;
+  float* out;
+  const uint32_t* rowinfo;
+  const uint32_t* ell;  // [pairs][N] pair-slot major (global)
+  int B, N, K, CO, Cin, Cout, pairs, act;
+};
+
+__device__ __forceinline__ void add4(float4& a, const float4& b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+
+// PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
+struct LdsConvDims {
+  int B, N, K, CO, Cin, Cout, pairs, act;
+};
+
+// Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
+// prove the weight loads are uniform + unclobbered and emit scalar s_load for them.
+// TCT > 0: block size fixed at compile time (the 512 x 10 configuration of the 5k level, so its
+// LDS offsets are immediates); TCT == 0: any block size <= 1024 (small levels run VPT = 1 or 2
+// with one thread slot per vertex, which gives 5..16 waves per CU for latency hiding).
+template <int CQ, int VPT, int TCT, int PW, bool BWD>
+__global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
+k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, const float* __restrict__ p_W,
+           const float* __restrict__ p_bias, float* __restrict__ p_out, const uint32_t* __restrict__ p_rowinfo,
+           const uint32_t* __restrict__ p_ell, LdsConvDims a) {
+  const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
+  const int VS = VPT * THREADS;  // vertex slots (> N)
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* slab = reinterpret_cast<float4*>(smem);             // [VS]; rows >= N stay zero
+  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);           // [VS][PW/4]
+
+  // blocks b and b+8 share an XCD: keep the slabs of one mesh on one L2 (speed only)
+  const int NS = (a.CO + 3) >> 2;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mesh = (jj / NS) * 8 + xcd, s0 = (jj % NS) * 4;
+  if (mesh >= a.B) return;  // uniform per block, before any barrier
+  const int tid = threadIdx.x, N = a.N;
+
+  {  // stage the ELL lists vertex-major; unused words point at the zero row N
+    const unsigned pad = (unsigned)N | ((unsigned)N << 16);
+    unsigned* ew = reinterpret_cast<unsigned*>(ellv);
+    for (int i = tid; i < VS * PW; i += THREADS) {
+      const int v = i / PW, p = i - v * PW;
+      ew[i] = (v < N && p < a.pairs) ? p_ell[p * N + v] : pad;
+    }
+  }
+
+  // ---- own vertices: -2/deg and the input rows scaled by s = deg^-1/2 (0 for slots past N)
+  float ka2[VPT];
+  float xs[VPT][CQ];
+  float4 R[VPT];
+  const float* inb = p_in + (long long)mesh * N * CQ;
+  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * N * CQ : nullptr;
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) {
+    const int v = tid + vi * THREADS;
+    const bool valid = v < N;
+    const int vl = min(v, N - 1);
+    const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
+    ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+    const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (CQ % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < CQ; c += 4) {
+        float4 t = *reinterpret_cast<const float4*>(inb + (long long)vl * CQ + c);
+        if (mkb) {
+          const float4 m = *reinterpret_cast<const float4*>(mkb + (long long)vl * CQ + c);
+          t.x = m.x > 0.f ? t.x : 0.f;
+          t.y = m.y > 0.f ? t.y : 0.f;
+          t.z = m.z > 0.f ? t.z : 0.f;
+          t.w = m.w > 0.f ? t.w : 0.f;
+        }
+        xs[vi][c] = t.x * s;
+        xs[vi][c + 1] = t.y * s;
+        xs[vi][c + 2] = t.z * s;
+        xs[vi][c + 3] = t.w * s;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        float t = inb[(long long)vl * CQ + c];
+        if (mkb && !(mkb[(long long)vl * CQ + c] > 0.f)) t = 0.f;
+        xs[vi][c] = t * s;
+      }
+    }
+  }
+
+  // acc[vi] += xs[vi][:] . W_k[:, slab]   (weights are wave-uniform: scalar loads, SGPR operands)
+  const bool slab_full = s0 + 4 <= a.CO;
+  const float* __restrict__ wslab = p_W + (long long)(s0 >> 2) * a.K * CQ * 4;
+  auto contract = [&](float4(&acc)[VPT], int k) {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      // p_W is the slab-packed copy [slab][k][c][4] (k_pack_w): contiguous, so one order's
+      // weights arrive in a few wide s_load instead of CQ*4 dependent scalar loads
+      const float* w = wslab + (k * CQ + c) * 4;
+#pragma unroll
+      for (int vi = 0; vi < VPT; ++vi) {
+        acc[vi].x = fmaf(xs[vi][c], w[0], acc[vi].x);
+        acc[vi].y = fmaf(xs[vi][c], w[1], acc[vi].y);
+        acc[vi].z = fmaf(xs[vi][c], w[2], acc[vi].z);
+        acc[vi].w = fmaf(xs[vi][c], w[3], acc[vi].w);
+      }
+    }
+  };
+  // acc[vi] += (scale * -2/deg) * sum_{j in N(v)} slab[j]
+  auto gather_axpy = [&](float4(&acc)[VPT], float scale) {
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < PW / 4; ++q) {
+        const uint4 id = ellv[v * (PW / 4) + q];
+        {
+          const float4 n0 = slab[id.x & 0xffffu], n1 = slab[id.x >> 16];
+          const float4 n2 = slab[id.y & 0xffffu], n3 = slab[id.y >> 16];
+          add4(g, n0);
+          add4(g, n1);
+          add4(g, n2);
+          add4(g, n3);
+        }
+        asm volatile("" ::: "memory");
+        {
+          const float4 n0 = slab[id.z & 0xffffu], n1 = slab[id.z >> 16];
+          const float4 n2 = slab[id.w & 0xffffu], n3 = slab[id.w >> 16];
+          add4(g, n0);
+          add4(g, n1);
+          add4(g, n2);
+          add4(g, n3);
+        }
+        asm volatile("" ::: "memory");
+      }
+      const float kk = ka2[vi] * scale;
+      acc[vi].x = fmaf(kk, g.x, acc[vi].x);
+      acc[vi].y = fmaf(kk, g.y, acc[vi].y);
+      acc[vi].z = fmaf(kk, g.z, acc[vi].z);
+      acc[vi].w = fmaf(kk, g.w, acc[vi].w);
+    }
+  };
+
+  if (a.K >= 2) {
+    contract(R, a.K - 1);
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      slab[tid + vi * THREADS] = R[vi];         // u_{K-1} (zero in the slots past N)
+      R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);  // u_K = 0
+    }
+    __syncthreads();  // slab + ELL staged
+    for (int k = a.K - 2; k >= 1; --k) {
+#pragma unroll
+      for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
+      contract(R, k);
+      gather_axpy(R, 1.0f);
+      __syncthreads();  // every gather of u_{k+1} is done
+#pragma unroll
+      for (int vi = 0; vi < VPT; ++vi) {
+        const int v = tid + vi * THREADS;
+        const float4 old = slab[v];
+        slab[v] = R[vi];
+        R[vi] = old;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
+    contract(R, 0);
+    gather_axpy(R, 0.5f);
+  } else {
+    contract(R, 0);
+  }
+
+  // ---- epilogue: unscale (1/s = sqrt(deg)), bias, activation, one store per vertex
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!BWD && p_bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (s0 + j < a.CO) bj[j] = p_bias[s0 + j];
+  }
+  float* outb = p_out + (long long)mesh * N * a.CO;
+  const bool vec_store = slab_full && (a.CO % 4 == 0);
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) {
+    const int v = tid + vi * THREADS;
+    if (v >= N) continue;
+    // -0.5 * ka2 = 1/deg  ->  rsq(1/deg) = sqrt(deg)
+    const float inv_s = ka2[vi] < 0.f ? __builtin_amdgcn_rsqf(-0.5f * ka2[vi]) : 1.0f;
+    float o[4] = {fmaf(R[vi].x, inv_s, bj[0]), fmaf(R[vi].y, inv_s, bj[1]), fmaf(R[vi].z, inv_s, bj[2]),
+                  fmaf(R[vi].w, inv_s, bj[3])};
+    if (!BWD && a.act == MVH_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    float* dst = outb + (long long)v * a.CO + s0;
+    if (vec_store) {
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (s0 + j < a.CO) dst[j] = o[j];
+    }
+  }
+}
+
+// Wp[slab][k][c][j] = W[k][c][4 slab + j] (forward) or W[k][4 slab + j][c] (backward, W^T);
+// entries past the last output channel are zero.  K*Cin*Cout <= ~10k floats: one tiny launch.
+__global__ void __launch_bounds__(256)
+k_pack_w(const float* __restrict__ W, float* __restrict__ Wp, int K, int Cin, int Cout, int CQ, int CO, int bwd) {
+  const int NS = (CO + 3) >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NS * K * CQ * 4) return;
+  const int j = i & 3, c = (i >> 2) % CQ, k = (i >> 2) / CQ % K, sl = (i >> 2) / CQ / K;
+  const int o = sl * 4 + j;
+  float v = 0.f;
+  if (o < CO) v = bwd ? W[((long long)k * Cin + o) * Cout + c] : W[((long long)k * Cin + c) * Cout + o];
+  Wp[i] = v;
+}
+
+static bool force_generic() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MESHVAE_FORCE_GENERIC");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+template <int CQ, int VPT, int TCT, int PW, bool BWD>
+static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
+  auto kern = k_cheb_lds<CQ, VPT, TCT, PW, BWD>;
+  const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    attr_bytes = lds;
+  }
+  const int NS = (a.CO + 3) / 4;
+  const int grid = ((a.B + 7) / 8) * 8 * NS;
+  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act};
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+template <int CQ, int VPT, int TCT>
+static int launch_cfg(hipStream_t st, const LdsConvArgs& a, bool bwd, int threads) {
+  if (a.pairs > 4)
+    return bwd ? launch_one<CQ, VPT, TCT, 8, true>(st, a, threads) : launch_one<CQ, VPT, TCT, 8, false>(st, a, threads);
+  return bwd ? launch_one<CQ, VPT, TCT, 4, true>(st, a, threads) : launch_one<CQ, VPT, TCT, 4, false>(st, a, threads);
+}
+
+template <int CQ>
+static int launch_cq(hipStream_t st, const LdsConvArgs& a, bool bwd, int vpt, int threads) {
+  if (vpt == 1) return launch_cfg<CQ, 1, 0>(st, a, bwd, threads);
+  if (vpt == 2) return launch_cfg<CQ, 2, 0>(st, a, bwd, threads);
+  if constexpr (CQ <= 16) {
+    if (vpt == 10 && threads == 512) return launch_cfg<CQ, 10, 512>(st, a, bwd, threads);
+  }
+  return -1;
+}
+
+// Returns MVH_OK and sets *handled when the LDS-resident kernel ran; *handled == false means
+// "not eligible, use the general pipeline".
+int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
+                 const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
+                 float* wpack, bool* handled) {
+  *handled = false;
+  if (!wpack) return MVH_OK;
+  if (force_generic()) return MVH_OK;
+  const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
+  if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
+    return MVH_OK;
+  const int CQ = bwd ? Cout : Cin, CO = bwd ? Cin : Cout;
+  if (N < 1 || N + 1 >= 65535) return MVH_OK;
+  if (CQ != 3 && CQ != 8 && CQ != 16 && CQ != 32) return MVH_OK;
+  if (((uintptr_t)in | (uintptr_t)mask | (uintptr_t)out) % 16 != 0) return MVH_OK;
+  // vertex slots: one thread per vertex while a block of <= 1024 threads covers the mesh (many
+  // waves hide the LDS latency), two per thread up to 2047 vertices, 512 x 10 for the 5k level
+  int vpt, threads;
+  if (N + 1 <= 1024) { vpt = 1; threads = ((N + 1 + 63) / 64) * 64; }
+  else if (N + 1 <= 2048) { vpt = 2; threads = (((N + 2) / 2 + 63) / 64) * 64; }
+  else if (N + 1 <= 5120 && CQ <= 16) { vpt = 10; threads = 512; }
+  else return MVH_OK;
+  const int pw = lap->ell_pairs > 4 ? 8 : 4;
+  if ((size_t)vpt * threads * (16 + pw * 4) > 160 * 1024) return MVH_OK;
+  const int n_pack = ((CO + 3) / 4) * K * CQ * 4;
+  if ((size_t)n_pack * sizeof(float) > kLdsWpackBytes) return MVH_OK;
+
+  LdsConvArgs a;
+  a.in = in; a.mask = mask; a.W = wpack; a.bias = bias; a.out = out;
+  a.rowinfo = lap->rowinfo; a.ell = lap->ell;
+  a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;
+  a.pairs = lap->ell_pairs; a.act = act;
+  // slab-packed weights for the scalar loads of the main kernel
+  hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
+  MVH_LAUNCH_CHECK();
+  int rc = -1;
+  if (CQ == 3) rc = launch_cq<3>(st, a, bwd, vpt, threads);
+  else if (CQ == 8) rc = launch_cq<8>(st, a, bwd, vpt, threads);
+  else if (CQ == 16) rc = launch_cq<16>(st, a, bwd, vpt, threads);
+  else rc = launch_cq<32>(st, a, bwd, vpt, threads);
+  if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_lds: no kernel for vpt=%d threads=%d", vpt, threads);
+  if (rc == MVH_OK) *handled = true;
+  return rc;
+}
+
+}  // namespace mvh

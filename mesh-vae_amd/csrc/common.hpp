@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "meshvae_hip.h"
@@ -43,5 +44,11 @@ int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, c
 int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
                 long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
                 int act, const float* drop_u, float p);
+
+// LDS-resident fused ChebConv (cheb_lds.hip); *handled == false -> caller uses the general pipeline
+int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
+                 const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
+                 float* wpack /* kLdsWpackBytes of scratch */, bool* handled);
+constexpr size_t kLdsWpackBytes = 64 * 1024;
 
 }  // namespace mvh

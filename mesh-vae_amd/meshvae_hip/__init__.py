@@ -19,9 +19,12 @@ class MeshVaeHipError(RuntimeError):
 class CsrStruct(ctypes.Structure):
     """mvh_csr_t"""
     _fields_ = [("n_rows", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("nnz", ctypes.c_int32),
-                ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p)]
+                ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
+                ("rowinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p), ("ell_pairs", ctypes.c_int32),
+                ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC = 1, 2
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 

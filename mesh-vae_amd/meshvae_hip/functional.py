@@ -93,18 +93,15 @@ class ChebConvFn(torch.autograd.Function):
             raise ValueError(f"Encountered node tensor with size {N} in dimension 0, "
                              f"but expected size {op.n_out}.")
         out = torch.empty(B, N, Cout, dtype=x.dtype, device=x.device)
-        need_grad = any(ctx.needs_input_grad[:3])
         L = lib()
         with torch.cuda.device(x.device):
             tx = None
             ws = None
             ws_bytes = 0
             if K > 1:
-                if need_grad:
-                    tx = torch.empty(K - 1, B, N, Cin, dtype=x.dtype, device=x.device)
-                else:
-                    ws_bytes = L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K)
-                    ws = workspace(ws_bytes, x.device)
+                # no T_k stack is saved: the fused kernels recompute the recurrence on chip
+                ws_bytes = L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K)
+                ws = workspace(ws_bytes, x.device)
             check(L.mvh_cheb_conv_fwd(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
                                       out.data_ptr(), _ptr(tx), B, N, Cin, Cout, K, act, _ptr(ws), ws_bytes))
         ctx.op, ctx.act, ctx.has_bias = op, act, bias is not None

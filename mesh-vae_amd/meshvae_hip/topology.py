@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from . import CsrStruct
+from . import CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CsrStruct
 
 
 class Csr:
@@ -31,11 +31,40 @@ class Csr:
         rowptr[1:] = torch.cumsum(counts, 0)
         self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(out_idx.numel())
         self.max_row_nnz = int(counts.max()) if counts.numel() else 0
+        col_sorted, val_sorted = in_idx[order], val[order].contiguous()
         self.rowptr = rowptr.to(torch.int32).to(device)
-        self.col = in_idx[order].to(torch.int32).to(device)
-        self.val = val[order].contiguous().to(device)
+        self.col = col_sorted.to(torch.int32).to(device)
+        self.val = val_sorted.to(device)
+        # ---- compact form + structure flags for the LDS-resident kernels (host analysis, once)
+        self.flags = 0
+        self.rowinfo = None
+        if self.n_rows == self.n_cols and self.nnz > 0:
+            deg = counts.to(torch.float32)
+            dis = deg.pow(-0.5)
+            dis[dis == float("inf")] = 0
+            rows_sorted = out_idx[order]
+            if torch.equal(val_sorted, -dis[col_sorted] * torch.ones_like(val_sorted) * dis[rows_sorted]):
+                self.flags |= CSR_NORMALIZED_LAPLACIAN
+            fwd_key = rows_sorted * self.n_cols + col_sorted
+            bwd_key = col_sorted * self.n_cols + rows_sorted
+            fo, bo = torch.sort(fwd_key).indices, torch.sort(bwd_key).indices
+            if torch.equal(fwd_key[fo], bwd_key[bo]) and torch.equal(val_sorted[fo], val_sorted[bo]):
+                self.flags |= CSR_SYMMETRIC
+        self.ell, self.ell_pairs = None, 0
+        if self.n_cols < 65535 and 0 < self.max_row_nnz < 256 and self.nnz < (1 << 24):
+            info = ((rowptr[:-1] << 8) | counts).numpy().astype("uint32")      # bit pattern kept in int32
+            self.rowinfo = torch.from_numpy(info.view("int32")).to(device)
+            self.ell_pairs = (self.max_row_nnz + 1) // 2
+            slots = torch.full((self.n_rows, 2 * self.ell_pairs), self.n_cols, dtype=torch.int64)
+            pos = torch.arange(self.nnz) - rowptr[:-1][out_idx[order]]          # position inside the row
+            slots[out_idx[order], pos] = col_sorted
+            packed = (slots[:, 0::2] | (slots[:, 1::2] << 16)).t().contiguous()  # [pairs, n_rows]
+            self.ell = torch.from_numpy(packed.numpy().astype("uint32").view("int32")).to(device)
         self.struct = CsrStruct(self.n_rows, self.n_cols, self.nnz, self.rowptr.data_ptr(),
-                                self.col.data_ptr(), self.val.data_ptr())
+                                self.col.data_ptr(), self.val.data_ptr(),
+                                self.rowinfo.data_ptr() if self.rowinfo is not None else None,
+                                self.ell.data_ptr() if self.ell is not None else None,
+                                self.ell_pairs, self.max_row_nnz, self.flags)
 
     @property
     def ref(self):
