@@ -321,6 +321,8 @@ extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, 
   size_t tx = align_up((size_t)(K > 1 ? K - 1 : 0) * rows * Cin * sizeof(float), 256);
   size_t g = align_up((size_t)K * rows * Cin * sizeof(float), 256);
   size_t part = align_up((size_t)dw_grid((long long)rows) * ((size_t)K * Cin + 1) * Cout * sizeof(float), 256);
+  const size_t part_lds = align_up(cheb_dw_lds_ws_bytes(B, N, Cin, Cout, K), 256);
+  if (part_lds > part) part = part_lds;
   return kLdsWpackBytes + tx + g + part + 256;
 }
 
@@ -350,12 +352,20 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
     if (db) MVH_HIP(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st));
     return MVH_OK;
   }
-  const float* tx = tx_saved;
-  if (!tx && K > 1) {
-    if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K)) return rc;
-    tx = tx_ws;
+  bool dw_done = false;
+  if (!tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
+    const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
+                                 partial, pbytes, &dw_done)) return rc;
   }
-  if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
+  if (!dw_done) {
+    const float* tx = tx_saved;
+    if (!tx && K > 1) {
+      if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K)) return rc;
+      tx = tx_ws;
+    }
+    if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
+  }
   if (!dx) return MVH_OK;
   {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
     bool handled = false;

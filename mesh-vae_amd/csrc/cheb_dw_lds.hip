@@ -1,0 +1,391 @@
+// LDS-resident weight gradient of ChebConv:  dW_k[ci][co] = sum_{b,v} T_k(L) x [b,v,ci] * dpre[b,v,co]
+// (the reference gets it from autograd through K matmuls, nn/conv.py:559-571).
+//
+// One side ("P", the one with FEWER channels) runs the Chebyshev recurrence, the other ("Q")
+// stays fixed:  dW_k = sum_v Q[v][q] * T_k(P)[v][p]   (L is symmetric, so T_k may act on either).
+// A workgroup owns (mesh, slab of 4 P-channels):
+//   * LDS   : t_k of the slab for every vertex as one float4 + the padded ELL neighbour lists --
+//             the same 160 KB image as the forward kernel (cheb_lds.hip), in scaled variables
+//             t~ = D^-1/2 T so the edge list needs no values;
+//   * recurrence: thread-owns-vertex, unweighted ds_read_b128 gathers, in-place swap of the
+//             previous order through registers, two barriers per order;
+//   * contraction over vertices on the MATRIX pipe: v_mfma_f32_4x4x1_16B_f32 with one block
+//             per vertex (4 lanes per vertex): A = 4 Q-channels of the vertex (pre-divided by s),
+//             B = its 4 slab values read back from LDS, so 16 vertices x (4x4) products per
+//             instruction accumulate straight into the dW tile -- no cross-lane reduction until
+//             the end of an order, and the VALU/LDS pipes stay free for the next order's gather;
+//   * Q rows live in VGPRs in that 4-lanes-per-vertex layout (read from HBM once per slab,
+//             1 KB contiguous per wave load).
+// Per (mesh, slab, wave, order) a 16 x 4 partial tile goes to a workspace; a second launch sums
+// the partials in fixed order (bitwise reproducible, no atomics) and scatters them into dW / db.
+#include "common.hpp"
+
+namespace mvh {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DwDims {
+  int B, N, K, CP, CQtot, pairs, db_mode;  // db_mode: 0 none, 1 = column sums of Q, 2 = of P
+};
+
+__device__ __forceinline__ void add4f(float4& a, const float4& b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+
+__device__ __forceinline__ float xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
+// part layout: [mesh][slab][wave][K+1][CQ][4]
+template <int CQ, int VPT, int TCT, int PW>
+__global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
+k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
+              const float* __restrict__ p_Qmask, const uint32_t* __restrict__ p_rowinfo,
+              const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, DwDims a) {
+  static_assert(CQ % 8 == 0, "Q channels are consumed 16 at a time (4 lanes x float4)");
+  constexpr int QH = (CQ + 15) / 16;  // float4 Q registers per vertex step per lane
+  const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
+  const int VS = VPT * THREADS;
+  const int NW = THREADS / 64;
+  constexpr int STEPS_CT = TCT > 0 ? (VPT * TCT / 16) / (TCT / 64) : VPT * 4;  // 16-vertex steps per wave
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* slab = reinterpret_cast<float4*>(smem);   // [VS]; rows >= N stay zero
+  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]
+  const float* slabf = reinterpret_cast<const float*>(slab);
+
+  const int NS = (a.CP + 3) >> 2;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mesh = (jj / NS) * 8 + xcd, sl = jj % NS, s0 = sl * 4;
+  if (mesh >= a.B) return;
+  const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
+
+  {
+    const unsigned pad = (unsigned)N | ((unsigned)N << 16);
+    unsigned* ew = reinterpret_cast<unsigned*>(ellv);
+    for (int i = tid; i < VS * PW; i += THREADS) {
+      const int v = i / PW, p = i - v * PW;
+      ew[i] = (v < N && p < a.pairs) ? p_ell[p * N + v] : pad;
+    }
+  }
+
+  // ---- Q rows in the MFMA layout: lane (b = lane>>2, i = lane&3) of step s holds
+  //      Q[v][16h + 4i .. +3] / s_v  for vertex v = 16 (s NW + wave) + b
+  float4 qreg[STEPS_CT][QH];
+  float4 qsum[QH];
+#pragma unroll
+  for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* Qb = p_Q + (long long)mesh * N * CQ;
+  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * N * CQ : nullptr;
+#pragma unroll
+  for (int s = 0; s < STEPS_CT; ++s) {
+    const int v = 16 * (s * NW + wave) + (lane >> 2);
+    const bool valid = v < N;
+    const int vl = min(v, N - 1);
+    const float deg = (float)(p_rowinfo[vl] & 255u);
+    const float inv_s = valid ? (deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f) : 0.f;
+#pragma unroll
+    for (int h = 0; h < QH; ++h) {
+      const int c0 = 16 * h + 4 * (lane & 3);
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 < CQ) {
+        t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
+        if (Qm) {
+          const float4 m = *reinterpret_cast<const float4*>(Qm + (long long)vl * CQ + c0);
+          t.x = m.x > 0.f ? t.x : 0.f;
+          t.y = m.y > 0.f ? t.y : 0.f;
+          t.z = m.z > 0.f ? t.z : 0.f;
+          t.w = m.w > 0.f ? t.w : 0.f;
+        }
+      }
+      if (valid) add4f(qsum[h], t);
+      qreg[s][h] = make_float4(t.x * inv_s, t.y * inv_s, t.z * inv_s, t.w * inv_s);
+    }
+  }
+
+  float* part = p_part + (((long long)mesh * NS + sl) * NW + wave) * (long long)(a.K + 1) * CQ * 4;
+  // bias gradient (plane K of the tile set, layout [q][j]): column sums of Q, written right away
+  if (a.db_mode == 1 && sl == 0) {  // lane (b, i) holds q = 16h + 4i + {0..3}
+    float* pk = part + (long long)a.K * CQ * 4;
+#pragma unroll
+    for (int h = 0; h < QH; ++h) {
+      float v4[4] = {qsum[h].x, qsum[h].y, qsum[h].z, qsum[h].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = v4[c];
+        x = xor_add(x, 4);
+        x = xor_add(x, 8);
+        x = xor_add(x, 16);
+        x = xor_add(x, 32);
+        const int q = 16 * h + 4 * lane + c;
+        if (lane < 4 && q < CQ) pk[q * 4] = x;
+      }
+    }
+  }
+
+  // ---- own vertices (thread-owns-vertex layout): t~_0 = s P[:, slab]
+  float ka2[VPT];
+  float4 R[VPT];
+  float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* Pb = p_P + (long long)mesh * N * a.CP;
+  const float* Pm = p_Pmask ? p_Pmask + (long long)mesh * N * a.CP : nullptr;
+  const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) {
+    const int v = tid + vi * THREADS;
+    const bool valid = v < N;
+    const int vl = min(v, N - 1);
+    const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
+    ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+    const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (slab_full) {
+      float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)vl * a.CP + s0);
+      if (Pm) {
+        const float4 m = *reinterpret_cast<const float4*>(Pm + (long long)vl * a.CP + s0);
+        tv.x = m.x > 0.f ? tv.x : 0.f;
+        tv.y = m.y > 0.f ? tv.y : 0.f;
+        tv.z = m.z > 0.f ? tv.z : 0.f;
+        tv.w = m.w > 0.f ? tv.w : 0.f;
+      }
+      t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (s0 + j < a.CP) {
+          float x = Pb[(long long)vl * a.CP + s0 + j];
+          if (Pm && !(Pm[(long long)vl * a.CP + s0 + j] > 0.f)) x = 0.f;
+          t[j] = x;
+        }
+    }
+    if (valid) {
+      psum.x += t[0]; psum.y += t[1]; psum.z += t[2]; psum.w += t[3];
+    }
+    slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);  // zero in the slots past N
+    R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (a.db_mode == 2) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
+    float* pk = part + (long long)a.K * CQ * 4;
+    float v4[4] = {psum.x, psum.y, psum.z, psum.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = v4[c];
+      x = xor_add(x, 1);
+      x = xor_add(x, 2);
+      x = xor_add(x, 4);
+      x = xor_add(x, 8);
+      x = xor_add(x, 16);
+      x = xor_add(x, 32);
+      if (lane == 0) pk[c] = x;
+    }
+  }
+  __syncthreads();  // slab = t~_0, ELL staged
+
+  auto gather = [&](int v) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < PW / 4; ++q) {
+      const uint4 id = ellv[v * (PW / 4) + q];
+      {
+        const float4 n0 = slab[id.x & 0xffffu], n1 = slab[id.x >> 16];
+        const float4 n2 = slab[id.y & 0xffffu], n3 = slab[id.y >> 16];
+        add4f(g, n0); add4f(g, n1); add4f(g, n2); add4f(g, n3);
+      }
+      asm volatile("" ::: "memory");
+      {
+        const float4 n0 = slab[id.z & 0xffffu], n1 = slab[id.z >> 16];
+        const float4 n2 = slab[id.w & 0xffffu], n3 = slab[id.w >> 16];
+        add4f(g, n0); add4f(g, n1); add4f(g, n2); add4f(g, n3);
+      }
+      asm volatile("" ::: "memory");
+    }
+    return g;
+  };
+
+  // dW tile of order k from the slab: 4 (x QH) MFMAs per 16 vertices, then one cross-block reduce
+  auto mfma_pass = [&](int k) {
+    f32x4 acc[QH][4];
+#pragma unroll
+    for (int h = 0; h < QH; ++h)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[h][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS_CT; ++s) {
+      const int v = 16 * (s * NW + wave) + (lane >> 2);
+      const float tb = slabf[v * 4 + (lane & 3)];
+#pragma unroll
+      for (int h = 0; h < QH; ++h) {
+        acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qreg[s][h].x, tb, acc[h][0], 0, 0, 0);
+        acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(qreg[s][h].y, tb, acc[h][1], 0, 0, 0);
+        acc[h][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(qreg[s][h].z, tb, acc[h][2], 0, 0, 0);
+        acc[h][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(qreg[s][h].w, tb, acc[h][3], 0, 0, 0);
+      }
+      if ((s & 3) == 3) asm volatile("" ::: "memory");  // at most 4 slab reads in flight (VGPR budget)
+    }
+    // lane (b, j), register r of acc[h][m]  =  sum over this block's vertices of
+    // Q~[v][16h + 4r + m] * t~_k[v][j]; fold the 16 blocks, lanes 0..3 write the tile
+#pragma unroll
+    for (int h = 0; h < QH; ++h)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[h][m][r];
+          x = xor_add(x, 4);
+          x = xor_add(x, 8);
+          x = xor_add(x, 16);
+          x = xor_add(x, 32);
+          const int q = 16 * h + 4 * r + m;
+          if (lane < 4 && q < CQ) part[((long long)k * CQ + q) * 4 + lane] = x;
+        }
+  };
+
+  mfma_pass(0);
+  for (int k = 1; k < a.K; ++k) {
+    const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const float4 g = gather(tid + vi * THREADS);
+      const float kk = ka2[vi] * sc;
+      R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
+                          fmaf(kk, g.w, -R[vi].w));
+    }
+    __syncthreads();  // all reads of t~_{k-1} (gathers and the previous MFMA pass) are done
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      const float4 old = slab[v];
+      slab[v] = R[vi];
+      R[vi] = old;
+    }
+    __syncthreads();
+    mfma_pass(k);
+  }
+
+}
+
+// Sum the per-(mesh, wave) partial tiles in fixed order and scatter into dW [K][Cin][Cout] / db.
+// One block = 64 consecutive tile entries x 4 partial groups.
+__global__ void __launch_bounds__(256)
+k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NWc, int NS, int K, int CQ, int CP, int p_is_x,
+            int Cin, int Cout, int db_mode, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int tile = (K + 1) * CQ * 4;           // floats per (mesh, slab, wave)
+  const int n_out = NS * tile;
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (o < n_out) {
+    const int sl = o / tile, e = o - sl * tile;
+    // p enumerates (mesh, wave) pairs in a fixed order
+    for (int p = grp; p < n_part; p += 4) {
+      const int mesh = p / NWc, wave = p - mesh * NWc;
+      s += part[(((long long)mesh * NS + sl) * NWc + wave) * tile + e];
+    }
+  }
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp != 0 || o >= n_out) return;
+  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int sl = o / tile, e = o - sl * tile;
+  const int k = e / (CQ * 4), q = (e / 4) % CQ, j = e & 3;
+  const int p = sl * 4 + j;
+  if (k < K) {
+    if (p >= CP) return;
+    const int ci = p_is_x ? p : q, co = p_is_x ? q : p;
+    dW[((long long)k * Cin + ci) * Cout + co] = s;
+  } else if (db) {
+    if (db_mode == 1 && sl == 0 && j == 0) db[q] = s;           // Q = dpre: db[co = q]
+    if (db_mode == 2 && q == 0 && p < CP) db[p] = s;             // P = dpre: db[co = p]
+  }
+}
+
+template <int CQ, int VPT, int TCT, int PW>
+static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
+                         const mvh_csr_t* lap, float* part, const DwDims& d, int threads) {
+  auto kern = k_cheb_dw_lds<CQ, VPT, TCT, PW>;
+  const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    attr_bytes = lds;
+  }
+  const int NS = (d.CP + 3) / 4;
+  const int grid = ((d.B + 7) / 8) * 8 * NS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+template <int CQ>
+static int launch_dw_cq(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
+                        const mvh_csr_t* lap, float* part, const DwDims& d, int vpt, int threads) {
+  const bool pw8 = d.pairs > 4;
+#define MVH_DW(V, T)                                                                                         \
+  return pw8 ? launch_dw_one<CQ, V, T, 8>(st, P, Pm, Q, Qm, lap, part, d, threads)                           \
+             : launch_dw_one<CQ, V, T, 4>(st, P, Pm, Q, Qm, lap, part, d, threads)
+  if (vpt == 1) { MVH_DW(1, 0); }
+  if (vpt == 2) { MVH_DW(2, 0); }
+  if constexpr (CQ <= 16) {
+    if (vpt == 10 && threads == 512) { MVH_DW(10, 512); }
+  }
+#undef MVH_DW
+  return -1;
+}
+
+size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
+  (void)N;
+  const int cq = Cin > Cout ? Cin : Cout, cp = Cin > Cout ? Cout : Cin;
+  // worst case 16 waves per block
+  return (size_t)B * ((cp + 3) / 4) * 16 * (size_t)(K + 1) * cq * 4 * sizeof(float) + 256;
+}
+
+// dW (+ db) through the LDS-resident kernels; *handled == false -> use the general pipeline.
+int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
+                    float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
+                    bool* handled) {
+  *handled = false;
+  const char* e = getenv("MESHVAE_FORCE_GENERIC");
+  if (e && e[0] == '1') return MVH_OK;
+  const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
+  if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
+    return MVH_OK;
+  if (N < 1 || N + 1 >= 65535 || B < 1) return MVH_OK;
+  // P = the side with fewer channels runs the recurrence (ties: x); Q stays in registers
+  const bool p_is_x = Cin <= Cout;
+  const int CP = p_is_x ? Cin : Cout, CQ = p_is_x ? Cout : Cin;
+  if (CQ != 8 && CQ != 16 && CQ != 32) return MVH_OK;
+  if (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)out_mask) % 16 != 0) return MVH_OK;
+  int vpt, threads;
+  if (N + 1 <= 1024) { vpt = 1; threads = ((N + 1 + 63) / 64) * 64; }
+  else if (N + 1 <= 2048) { vpt = 2; threads = (((N + 2) / 2 + 63) / 64) * 64; }
+  else if (N + 1 <= 5120 && CQ <= 16) { vpt = 10; threads = 512; }
+  else return MVH_OK;
+  const int pw = lap->ell_pairs > 4 ? 8 : 4;
+  if ((size_t)vpt * threads * (16 + pw * 4) > 160 * 1024) return MVH_OK;
+  const int NS = (CP + 3) / 4, NW = threads / 64;
+  const size_t need_bytes = (size_t)B * NS * NW * (K + 1) * CQ * 4 * sizeof(float);
+  if (!part || part_bytes < need_bytes) return MVH_OK;
+
+  DwDims d;
+  d.B = B; d.N = N; d.K = K; d.CP = CP; d.CQtot = CQ; d.pairs = lap->ell_pairs;
+  d.db_mode = db ? (p_is_x ? 1 : 2) : 0;
+  const float* P = p_is_x ? x : dout;
+  const float* Pm = p_is_x ? nullptr : out_mask;
+  const float* Q = p_is_x ? dout : x;
+  const float* Qm = p_is_x ? out_mask : nullptr;
+  int rc;
+  if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
+  else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
+  else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
+  if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
+  if (rc) return rc;
+  const int n_out = NS * (K + 1) * CQ * 4;
+  hipLaunchKernelGGL(k_dw_reduce, dim3(cdiv(n_out, 64)), dim3(256), 0, st, part, B * NW, NW, NS, K, CQ, CP,
+                     p_is_x ? 1 : 0, Cin, Cout, d.db_mode, dW, db);
+  MVH_LAUNCH_CHECK();
+  *handled = true;
+  return MVH_OK;
+}
+
+}  // namespace mvh

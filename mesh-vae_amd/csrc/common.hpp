@@ -50,5 +50,10 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
+// LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
+size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
+int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
+                    float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
+                    bool* handled);
 
 }  // namespace mvh
