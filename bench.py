@@ -57,9 +57,10 @@ def time_kernel(fn, iters=30, warm=5):
 
 
 def kernel_rooflines(net, B, dev):
-    """Per-kernel algorithmic bytes / measured duration for the level-0 kernels of one step.
-    Algorithmic bytes = each operand of the launch read or written exactly once."""
-    import ctypes
+    """Algorithmic bytes / measured duration of the level-0 (4998-vertex, 16-channel) kernels.
+    Algorithmic bytes = every operand of the launch read or written exactly once (DESIGN.md 5);
+    durations are HIP-event averages on the launching stream.  Each op below is one dominant
+    kernel plus a <= 5 us helper launch (weight packing / partial-sum reduce), named in the key."""
     from meshvae_hip import check, lib
     from meshvae_hip.functional import workspace
     L = lib()
@@ -67,9 +68,8 @@ def kernel_rooflines(net, B, dev):
     lap = net._lap[0]
     N, C, K, Cout = net.num_nodes[0], 16, 6, 16
     st = torch.cuda.current_stream(dev).cuda_stream
-    plane = B * N * C
+    plane = B * N * C * 4                                   # bytes of one [B, N, 16] fp32 tensor
     x = torch.randn(B, N, C, device=dev)
-    tx = torch.randn(K - 1, B, N, C, device=dev)
     out = torch.randn(B, N, Cout, device=dev)
     dout = torch.randn(B, N, Cout, device=dev)
     W = torch.randn(K, C, Cout, device=dev) * 0.1
@@ -79,23 +79,25 @@ def kernel_rooflines(net, B, dev):
     ws = workspace(ws_b, dev)
     res = {}
 
-    def spmm():
-        check(L.mvh_spmm(st, lap.fwd.ref, tx[0].data_ptr(), tx[1].data_ptr(), None, x.data_ptr(), 2.0, -1.0, B, C, 0))
-    ms = time_kernel(spmm)
-    res["k_spmm<4,false> (L0, 16ch recurrence step)"] = dict(ms=ms, bytes=3 * plane * 4 + lap.fwd.nnz * 8, launches_per_step=30)
-
     def fwd():
         check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                   None, B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
-    ms_f = time_kernel(fwd)
-    res["mvh_cheb_conv_fwd (L0 16->16, all launches)"] = dict(ms=ms_f, bytes=2 * plane * 4, launches_per_step=1)
+    res["k_cheb_lds<16,10,512,4,false> (+k_pack_w): conv fwd L0 16->16"] = dict(
+        ms=time_kernel(fwd), bytes=2 * plane, launches_per_step=2)          # read x, write out
+
+    def bwd_dw():
+        check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                  dout.data_ptr(), None, None, dW.data_ptr(), db.data_ptr(),
+                                  B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
+    res["k_cheb_dw_lds<16,10,512,4> (+k_dw_reduce): conv dW/db L0 16->16"] = dict(
+        ms=time_kernel(bwd_dw), bytes=3 * plane, launches_per_step=3)       # read x, dout, relu mask
 
     def bwd():
         check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
                                   dout.data_ptr(), None, dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
                                   B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
-    ms_b = time_kernel(bwd)
-    res["mvh_cheb_conv_bwd (L0 16->16, all launches)"] = dict(ms=ms_b, bytes=4 * plane * 4, launches_per_step=1)
+    res["mvh_cheb_conv_bwd L0 16->16 (dW + dX kernels)"] = dict(
+        ms=time_kernel(bwd), bytes=6 * plane, launches_per_step=1)          # dW pass 3 planes + dX pass 3 planes
     return res
 
 
@@ -215,6 +217,7 @@ def main():
         if not args.no_kernel_roofline:
             ks = kernel_rooflines(net, B, dev)
             name = max((k for k in ks if k.startswith("k_")), key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
+            # (the dominant kernel of the step by total time: see profiles/ for the rocprofv3 view)
             d = ks[name]
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,

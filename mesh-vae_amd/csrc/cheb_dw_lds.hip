@@ -37,7 +37,23 @@ __device__ __forceinline__ void add4f(float4& a, const float4& b) {
 
 __device__ __forceinline__ float xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
-// part layout: [mesh][slab][wave][K+1][CQ][4]
+// v + (v rotated right by N lanes inside each row of 16): a VALU DPP op, no LDS round trip
+template <int N>
+__device__ __forceinline__ float row_ror_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false);
+  return v + __int_as_float(r);
+}
+
+// sum over the 16 lanes that share (lane & 3): two in-row DPP rotations, then the 4 rows
+__device__ __forceinline__ float sum_blocks(float x) {
+  x = row_ror_add<4>(x);
+  x = row_ror_add<8>(x);
+  x = xor_add(x, 16);
+  x = xor_add(x, 32);
+  return x;
+}
+
+// part layout: [slab][mesh][wave][K+1][CQ][4]
 template <int CQ, int VPT, int TCT, int PW>
 __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
@@ -103,7 +119,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   }
 
-  float* part = p_part + (((long long)mesh * NS + sl) * NW + wave) * (long long)(a.K + 1) * CQ * 4;
+  float* part = p_part + (((long long)sl * a.B + mesh) * NW + wave) * (long long)(a.K + 1) * CQ * 4;
   // bias gradient (plane K of the tile set, layout [q][j]): column sums of Q, written right away
   if (a.db_mode == 1 && sl == 0) {  // lane (b, i) holds q = 16h + 4i + {0..3}
     float* pk = part + (long long)a.K * CQ * 4;
@@ -113,10 +129,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float x = v4[c];
-        x = xor_add(x, 4);
-        x = xor_add(x, 8);
-        x = xor_add(x, 16);
-        x = xor_add(x, 32);
+        x = sum_blocks(x);
         const int q = 16 * h + 4 * lane + c;
         if (lane < 4 && q < CQ) pk[q * 4] = x;
       }
@@ -231,10 +244,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float x = acc[h][m][r];
-          x = xor_add(x, 4);
-          x = xor_add(x, 8);
-          x = xor_add(x, 16);
-          x = xor_add(x, 32);
+          x = sum_blocks(x);
           const int q = 16 * h + 4 * r + m;
           if (lane < 4 && q < CQ) part[((long long)k * CQ + q) * 4 + lane] = x;
         }
@@ -265,27 +275,35 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 }
 
 // Sum the per-(mesh, wave) partial tiles in fixed order and scatter into dW [K][Cin][Cout] / db.
-// One block = 64 consecutive tile entries x 4 partial groups.
-__global__ void __launch_bounds__(256)
-k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NWc, int NS, int K, int CQ, int CP, int p_is_x,
+// part layout [slab][mesh*NW + wave][tile]; one block = 64 consecutive tile entries x 16 groups
+// of partials, every thread keeps 4 independent running sums (loads pipelined, fixed order).
+__global__ void __launch_bounds__(1024)
+k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NS, int K, int CQ, int CP, int p_is_x,
             int Cin, int Cout, int db_mode, float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float red[4][64];
-  const int tile = (K + 1) * CQ * 4;           // floats per (mesh, slab, wave)
+  __shared__ float red[16][64];
+  const int tile = (K + 1) * CQ * 4;  // floats per (slab, mesh, wave)
   const int n_out = NS * tile;
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  float s = 0.f;
+  const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lo;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (o < n_out) {
     const int sl = o / tile, e = o - sl * tile;
-    // p enumerates (mesh, wave) pairs in a fixed order
-    for (int p = grp; p < n_part; p += 4) {
-      const int mesh = p / NWc, wave = p - mesh * NWc;
-      s += part[(((long long)mesh * NS + sl) * NWc + wave) * tile + e];
+    const float* src = part + (long long)sl * n_part * tile + e;
+    int p = grp;
+    for (; p + 48 < n_part; p += 64) {
+      s0 += src[(long long)p * tile];
+      s1 += src[(long long)(p + 16) * tile];
+      s2 += src[(long long)(p + 32) * tile];
+      s3 += src[(long long)(p + 48) * tile];
     }
+    for (; p < n_part; p += 16) s0 += src[(long long)p * tile];
   }
-  red[grp][threadIdx.x & 63] = s;
+  red[grp][lo] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp != 0 || o >= n_out) return;
-  s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += red[g][lo];
   const int sl = o / tile, e = o - sl * tile;
   const int k = e / (CQ * 4), q = (e / 4) % CQ, j = e & 3;
   const int p = sl * 4 + j;
@@ -294,8 +312,8 @@ k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NWc, int 
     const int ci = p_is_x ? p : q, co = p_is_x ? q : p;
     dW[((long long)k * Cin + ci) * Cout + co] = s;
   } else if (db) {
-    if (db_mode == 1 && sl == 0 && j == 0) db[q] = s;           // Q = dpre: db[co = q]
-    if (db_mode == 2 && q == 0 && p < CP) db[p] = s;             // P = dpre: db[co = p]
+    if (db_mode == 1 && sl == 0 && j == 0) db[q] = s;  // Q = dpre: db[co = q]
+    if (db_mode == 2 && q == 0 && p < CP) db[p] = s;    // P = dpre: db[co = p]
   }
 }
 
@@ -381,7 +399,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
   if (rc) return rc;
   const int n_out = NS * (K + 1) * CQ * 4;
-  hipLaunchKernelGGL(k_dw_reduce, dim3(cdiv(n_out, 64)), dim3(256), 0, st, part, B * NW, NW, NS, K, CQ, CP,
+  hipLaunchKernelGGL(k_dw_reduce, dim3(cdiv(n_out, 64)), dim3(1024), 0, st, part, B * NW, NS, K, CQ, CP,
                      p_is_x ? 1 : 0, Cin, Cout, d.db_mode, dW, db);
   MVH_LAUNCH_CHECK();
   *handled = true;

@@ -6,65 +6,93 @@
 
 namespace mvh {
 
-// ------------------------------------------------------------------ small strided GEMM
-constexpr int TM = 32, TN = 32, TK = 32;
+// ------------------------------------------------------------------ small strided GEMM (MFMA)
+// C[M,N] = sum_k A(m,k) B(k,n) with A(m,k) = A[m*sam + k*sak], B(k,n) = Bm[k*sbk + n*sbn]
+// (+bias[n]) -> act -> dropout.  The FC layers are skinny (M = batch = 64): one wave owns a
+// 16x16 output tile and runs the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32 over K
+// (lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]); operands that are contiguous
+// in K are fetched as 16-byte vectors covering four k-steps (the k order inside a 16-chunk is
+// permuted identically for A and B, which a dot product does not care about).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256)
-k_gemm(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm,
-       long long sbk, long long sbn, float* __restrict__ C, int M, int N, int K,
-       const float* __restrict__ bias, int act, const float* __restrict__ drop_u, float p) {
-  __shared__ float As[TK][TM + 1];
-  __shared__ float Bs[TK][TN + 1];
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
-  for (int k0 = 0; k0 < K; k0 += TK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = threadIdx.x + i * 256;
-      int kk, mm;
-      if (a_kfast) { kk = e % TK; mm = e / TK; } else { mm = e % TM; kk = e / TM; }
-      const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-      int kb, nn;
-      if (b_nfast) { nn = e % TN; kb = e / TN; } else { kb = e % TK; nn = e / TK; }
-      const int n = n0 + nn, k2 = k0 + kb;
-      Bs[kb][nn] = (n < N && k2 < K) ? Bm[k2 * sbk + n * sbn] : 0.f;
+template <bool KC>
+__device__ __forceinline__ void load_k4(const float* __restrict__ base, long long s_row, long long s_k, int row,
+                                        int nrows, int k, int K, float (&v)[4]) {
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+  if (row >= nrows) return;
+  const float* p = base + (long long)row * s_row;
+  if constexpr (KC) {
+    if (k + 3 < K) {
+      const float4 t = *reinterpret_cast<const float4*>(p + k);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      return;
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < TK; ++kk) {
-      const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
-      const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
-      acc[0][0] = fmaf(a0, b0, acc[0][0]);
-      acc[0][1] = fmaf(a0, b1, acc[0][1]);
-      acc[1][0] = fmaf(a1, b0, acc[1][0]);
-      acc[1][1] = fmaf(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
   }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (k + t < K) v[t] = p[(long long)(k + t) * s_k];
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256)
+k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm, long long sbk,
+         long long sbn, float* __restrict__ C, int M, int N, int K, const float* __restrict__ bias, int act,
+         const float* __restrict__ drop_u, float p) {
+  // one block = one 16x16 output tile; its 4 waves split K (interleaved 16-chunks) and are
+  // summed through LDS in fixed order, so the dependent-load chain per wave is K/64 long
+  __shared__ float red[3][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int i = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k0 = wave * 16; k0 < K; k0 += 64) {
+    float a[4], b[4];
+    load_k4<A_KC>(A, sam, sak, m0 + i, M, k0 + 4 * kq, K, a);
+    load_k4<B_KC>(Bm, sbn, sbk, n0 + i, N, k0 + 4 * kq, K, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
   const float keep_scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+  const int n = n0 + i;
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
-      if (m >= M || n >= N) continue;
-      float v = acc[i][j];
-      if (bias) v += bias[n];
-      if (act == MVH_ACT_RELU) v = fmaxf(v, 0.f);
-      if (drop_u && p > 0.f) v = (drop_u[(long long)m * N + n] >= p) ? v * keep_scale : 0.f;
-      C[(long long)m * N + n] = v;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * kq + r;
+    if (m >= M) continue;
+    float v = acc[r] + bv;
+    if (act == MVH_ACT_RELU) v = fmaxf(v, 0.f);
+    if (drop_u && p > 0.f) v = (drop_u[(long long)m * N + n] >= p) ? v * keep_scale : 0.f;
+    C[(long long)m * N + n] = v;
+  }
 }
 
 int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
                 long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
                 int act, const float* drop_u, float p) {
   if (M == 0 || N == 0) return MVH_OK;
-  hipLaunchKernelGGL(k_gemm, dim3(cdiv(N, TN), cdiv(M, TM)), dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn,
-                     C, M, N, K, bias, act, drop_u, p);
+  const bool akc = (sak == 1) && (sam % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  const bool bkc = (sbk == 1) && (sbn % 4 == 0) && ((uintptr_t)Bm % 16 == 0);
+  const dim3 grid(cdiv(N, 16), cdiv(M, 16));
+#define MVH_GEMM(AK, BK)                                                                                   \
+  hipLaunchKernelGGL((k_gemm16<AK, BK>), grid, dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
+                     act, drop_u, p)
+  if (akc && bkc) MVH_GEMM(true, true);
+  else if (akc) MVH_GEMM(true, false);
+  else if (bkc) MVH_GEMM(false, true);
+  else MVH_GEMM(false, false);
+#undef MVH_GEMM
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
