@@ -106,6 +106,7 @@ class TrainStep:
         self.graph_fb = self.graph_opt = None
         self.out = None
         net._eps_provider = lambda B, Z, device: self.eps      # static buffer (graph-safe)
+        net._prepare()                                         # topology upload must precede any capture
 
     def load(self, x, x_gt, y):
         self.x.copy_(x, non_blocking=True)
@@ -122,7 +123,7 @@ class TrainStep:
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):         # first call allocates workspaces / sets kernel attributes
                 self._draw_eps()
                 self._fwd_bwd()
         torch.cuda.current_stream(self.dev).wait_stream(side)
