@@ -106,7 +106,8 @@ int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, const float* x,
  * the ReLU mask when act == MVH_ACT_RELU, may be NULL otherwise).  `lap_t` is the CSR of
  * L^T (== lap for the symmetric mesh Laplacian).  tx_saved may be NULL (T_k recomputed).
  * dx may be NULL (first layer).  dW [K,Cin,Cout] and db [Cout] (NULL if no bias) are
- * overwritten (not accumulated). */
+ * overwritten (not accumulated); dW may be NULL for a dX-only call (dW and dX are independent
+ * and may run on different streams with separate workspaces). */
 size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K);
 int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
                       const float* x, const float* W, const float* out, const float* dout,
@@ -171,6 +172,49 @@ int mvh_vae_loss_bwd(mvh_stream_t stream, const float* recon, const void* x_gt, 
 int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
                   float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float grad_scale, int32_t* step_count);
+
+/* ---- row F: cheb_VAE.forward (cheb_VAE.py:190-251) and loss.backward() (main.py:80) as one
+ * native launch sequence.  `desc` describes the model the reference builds in
+ * cheb_VAE.__init__ (cheb_VAE.py:106-172): filters = [num_features] + num_conv_filters,
+ * K = polygon_order, the per-level operators in the CSR form above.  lap[i] (i < n_layers)
+ * is the level-i Laplacian; lap[n_layers] is the COARSEST edge list on the FINEST vertex set
+ * (the final layer's quirk, cheb_VAE.py:288).  down[i]/up[i] map level i <-> i+1; *_t are the
+ * transposes.  `params` / `grads` are host arrays of mvh_vae_param_count() device pointers in
+ * state_dict order (cheb.i.{weight,bias}, cheb_dec.i.{weight,bias}, cheb_dec.n.weight,
+ * classifier_layer, z_mean, z_log_var, enc_lin, dec_lin, dec_lin_1, dec_lin_2 .{weight,bias}).
+ * y is the one-hot label as float [B,C]; eps [B,Z] host-drawn N(0,1) or NULL (m_type="test");
+ * drop_u [B*(3H + flat)] uniforms for the four dropout sites in order (encoder h, classifier,
+ * dec_lin, dec_lin_2), NULL = eval.  Activations and their gradients live in `ws`
+ * (mvh_vae_step_ws_bytes), which must be passed unchanged from forward to backward.
+ * backward overwrites every gradient (dec_lin_1: zeros); its weight-gradient kernels run on an
+ * internal side stream forked from and joined to `stream` with events (hipGraph-capturable). */
+#define MVH_VAE_MAX_LAYERS 8
+typedef struct mvh_vae_desc {
+  int32_t n_layers, num_features, num_hidden, num_classes, num_style;
+  float dropout_p;
+  int32_t filters[MVH_VAE_MAX_LAYERS + 2];
+  int32_t K[MVH_VAE_MAX_LAYERS + 1];
+  int32_t num_nodes[MVH_VAE_MAX_LAYERS + 1];
+  mvh_csr_t lap[MVH_VAE_MAX_LAYERS + 1], lap_t[MVH_VAE_MAX_LAYERS + 1];
+  mvh_csr_t down[MVH_VAE_MAX_LAYERS], down_t[MVH_VAE_MAX_LAYERS];
+  mvh_csr_t up[MVH_VAE_MAX_LAYERS], up_t[MVH_VAE_MAX_LAYERS];
+} mvh_vae_desc_t;
+
+/* struct sizes as compiled (binding self-check) */
+size_t mvh_sizeof_vae_desc(void);
+size_t mvh_sizeof_csr(void);
+size_t mvh_vae_step_ws_bytes(const mvh_vae_desc_t* desc, int32_t B);
+int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc);
+int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* const* params,
+                    const float* x, const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
+                    const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
+                    float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu, float* logvar,
+                    void* ws, size_t ws_bytes);
+int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* const* params,
+                     float* const* grads, const float* x, const float* y, const void* x_gt, int32_t gt_f64,
+                     const float* eps, const float* drop_u, int32_t B, float log_sigma, const void* d_loss,
+                     const float* recon, const float* y_hat, const float* mu, const float* logvar,
+                     void* ws, size_t ws_bytes, mvh_stream_t side_stream /* NULL = internal */);
 
 #ifdef __cplusplus
 }

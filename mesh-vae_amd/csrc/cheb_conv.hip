@@ -334,7 +334,7 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
-  MVH_REQUIRE(x && W && dout && dW, "cheb_conv_bwd: null tensor");
+  MVH_REQUIRE(x && W && dout && (dW || dx), "cheb_conv_bwd: null tensor");
   MVH_REQUIRE(act != MVH_ACT_RELU || out, "cheb_conv_bwd: relu backward needs the forward output");
   MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -348,12 +348,12 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   p += align_up((size_t)K * plane * sizeof(float), 256);
   float* partial = (float*)p;
   if (rows == 0) {
-    MVH_HIP(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
+    if (dW) MVH_HIP(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
     if (db) MVH_HIP(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st));
     return MVH_OK;
   }
-  bool dw_done = false;
-  if (!tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
+  bool dw_done = (dW == nullptr);  // dW == NULL: dX-only call (the step engine runs dW on a side stream)
+  if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
                                  partial, pbytes, &dw_done)) return rc;

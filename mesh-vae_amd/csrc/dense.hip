@@ -112,9 +112,16 @@ __global__ void __launch_bounds__(256)
 k_colsum(const float* __restrict__ a, float* __restrict__ out, int M, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  float s = 0.f;
-  for (int m = 0; m < M; ++m) s += a[(long long)m * N + n];
-  out[n] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // independent chains: loads pipeline, order fixed
+  int m = 0;
+  for (; m + 3 < M; m += 4) {
+    s0 += a[(long long)m * N + n];
+    s1 += a[(long long)(m + 1) * N + n];
+    s2 += a[(long long)(m + 2) * N + n];
+    s3 += a[(long long)(m + 3) * N + n];
+  }
+  for (; m < M; ++m) s0 += a[(long long)m * N + n];
+  out[n] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------ latent head, forward
@@ -124,7 +131,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const float* __restrict__ drop_u,
              float p, const float* __restrict__ Wc, const float* __restrict__ bc,
              const float* __restrict__ Wm, const float* __restrict__ bm, const float* __restrict__ Wv,
@@ -236,20 +243,34 @@ k_latent_wgrad(const float* __restrict__ h, const float* __restrict__ y, const f
   float s = 0.f;
   if (o < C) {
     if (j > H) return;  // classifier input is only [H] (+ bias slot at j == H)
-    for (int b = 0; b < B; ++b) {
-      float in = 1.f;
-      if (j < H) {
-        in = h[(long long)b * H + j];
-        if (drop_u && p > 0.f) in = (drop_u[(long long)b * H + j] >= p) ? in * scale : 0.f;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int b = b0 + t;
+        if (b >= B) break;
+        float in = 1.f;
+        if (j < H) {
+          in = h[(long long)b * H + j];
+          if (drop_u && p > 0.f) in = (drop_u[(long long)b * H + j] >= p) ? in * scale : 0.f;
+        }
+        s4[t] = fmaf(dpre[(long long)b * no + o], in, s4[t]);
       }
-      s = fmaf(dpre[(long long)b * no + o], in, s);
     }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     if (j < H) dWc[(long long)o * H + j] = s; else dbc[o] = s;
   } else {
-    for (int b = 0; b < B; ++b) {
-      const float in = (j == ld) ? 1.f : (j < C ? y[(long long)b * C + j] : h[(long long)b * H + (j - C)]);
-      s = fmaf(dpre[(long long)b * no + o], in, s);
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int b = b0 + t;
+        if (b >= B) break;
+        const float in = (j == ld) ? 1.f : (j < C ? y[(long long)b * C + j] : h[(long long)b * H + (j - C)]);
+        s4[t] = fmaf(dpre[(long long)b * no + o], in, s4[t]);
+      }
     }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     const int zz = (o - C) % Z;
     const bool is_mu = (o - C) < Z;
     if (j < ld) (is_mu ? dWm : dWv)[(long long)zz * ld + j] = s;
@@ -309,7 +330,7 @@ extern "C" int mvh_vae_latent_fwd(mvh_stream_t stream, const float* h, const flo
   if (B == 0) return MVH_OK;
   const size_t lds = (size_t)(C + H + H + C + 2 * Z) * sizeof(float);
   MVH_REQUIRE(lds <= 64 * 1024, "latent_fwd: hidden size %d too large", H);
-  hipLaunchKernelGGL(k_latent_fwd, dim3(B), dim3(256), lds, (hipStream_t)stream, h, y, drop_u, p, Wc, bc, Wm,
+  hipLaunchKernelGGL(k_latent_fwd, dim3(B), dim3(1024), lds, (hipStream_t)stream, h, y, drop_u, p, Wc, bc, Wm,
                      bm, Wv, bv, eps, y_hat, mu, logvar, z, zy, H, C, Z);
   MVH_LAUNCH_CHECK();
   return MVH_OK;

@@ -47,7 +47,36 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  for (int e = e0; e < e1; ++e) {
+  int e = e0;
+  if constexpr (VEC == 4) {
+    // four independent gathers in flight per lane (long rows, e.g. the transposed upsampling
+    // operator with ~12 taps per row, are otherwise one dependent HBM/L2 round trip per tap);
+    // the adds stay in edge order, so EXACT results are unchanged
+    for (; e + 3 < e1; e += 4) {
+      const int c0 = col[e], c1 = col[e + 1], c2 = col[e + 2], c3 = col[e + 3];
+      const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
+      const float4 x0 = *reinterpret_cast<const float4*>(xb + (long long)c0 * C);
+      const float4 x1 = *reinterpret_cast<const float4*>(xb + (long long)c1 * C);
+      const float4 x2 = *reinterpret_cast<const float4*>(xb + (long long)c2 * C);
+      const float4 x3 = *reinterpret_cast<const float4*>(xb + (long long)c3 * C);
+      mac<EXACT>(acc[0], v0, x0.x); mac<EXACT>(acc[1], v0, x0.y); mac<EXACT>(acc[2], v0, x0.z); mac<EXACT>(acc[3], v0, x0.w);
+      mac<EXACT>(acc[0], v1, x1.x); mac<EXACT>(acc[1], v1, x1.y); mac<EXACT>(acc[2], v1, x1.z); mac<EXACT>(acc[3], v1, x1.w);
+      mac<EXACT>(acc[0], v2, x2.x); mac<EXACT>(acc[1], v2, x2.y); mac<EXACT>(acc[2], v2, x2.z); mac<EXACT>(acc[3], v2, x2.w);
+      mac<EXACT>(acc[0], v3, x3.x); mac<EXACT>(acc[1], v3, x3.y); mac<EXACT>(acc[2], v3, x3.z); mac<EXACT>(acc[3], v3, x3.w);
+    }
+    if (e + 2 < e1) {  // exactly three left: the barycentric upsampling row (nn/pool.py U: 3 taps)
+      const int c0 = col[e], c1 = col[e + 1], c2 = col[e + 2];
+      const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2];
+      const float4 x0 = *reinterpret_cast<const float4*>(xb + (long long)c0 * C);
+      const float4 x1 = *reinterpret_cast<const float4*>(xb + (long long)c1 * C);
+      const float4 x2 = *reinterpret_cast<const float4*>(xb + (long long)c2 * C);
+      mac<EXACT>(acc[0], v0, x0.x); mac<EXACT>(acc[1], v0, x0.y); mac<EXACT>(acc[2], v0, x0.z); mac<EXACT>(acc[3], v0, x0.w);
+      mac<EXACT>(acc[0], v1, x1.x); mac<EXACT>(acc[1], v1, x1.y); mac<EXACT>(acc[2], v1, x1.z); mac<EXACT>(acc[3], v1, x1.w);
+      mac<EXACT>(acc[0], v2, x2.x); mac<EXACT>(acc[1], v2, x2.y); mac<EXACT>(acc[2], v2, x2.z); mac<EXACT>(acc[3], v2, x2.w);
+      e += 3;
+    }
+  }
+  for (; e < e1; ++e) {
     const int c = col[e];
     const float v = val[e];
     if constexpr (VEC == 4) {

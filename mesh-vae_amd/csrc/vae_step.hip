@@ -1,0 +1,297 @@
+// Row F: cheb_VAE.forward (cheb_VAE.py:190-251) + loss.backward() (main.py:80) as ONE native
+// launch sequence: every kernel of the forward and of the analytic backward is enqueued from
+// C++ with activations / gradients in a caller-provided workspace and parameter gradients
+// written straight into the caller's (flat) gradient buffer -- no framework glue kernels, no
+// autograd graph.  The weight-gradient kernels depend only on (layer input, layer dout), so the
+// backward forks them onto a side stream and the critical path is just the dX chain; the fork /
+// join uses events only, so the whole step is capturable into one hipGraph.
+#include <vector>
+
+#include "common.hpp"
+
+namespace mvh {
+
+struct Buf {
+  size_t off;  // byte offset into the workspace
+};
+
+struct StepPlan {
+  int n, B, H, C, Z, F0, flat;
+  std::vector<int> Nn;            // vertices per level [n+1]
+  std::vector<int> f;             // filters [n+2]
+  // activations (floats): conv outputs / pooled, decoder unpooled / conv outputs
+  std::vector<size_t> encA, encP, decU, decC, g_encA, g_encP, g_decU, g_decC;
+  size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat;
+  size_t scratch_main, scratch_side, scratch_bytes;
+  size_t total;
+};
+
+static size_t take(size_t& cur, size_t floats) {
+  const size_t o = cur;
+  cur += align_up(floats * sizeof(float), 256);
+  return o;
+}
+
+static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
+  MVH_REQUIRE(d && d->n_layers >= 1 && d->n_layers <= MVH_VAE_MAX_LAYERS, "vae_step: bad n_layers");
+  p.n = d->n_layers; p.B = B; p.H = d->num_hidden; p.C = d->num_classes; p.Z = d->num_style;
+  p.F0 = d->filters[0];
+  p.Nn.assign(d->num_nodes, d->num_nodes + p.n + 1);
+  p.f.assign(d->filters, d->filters + p.n + 2);
+  p.flat = p.Nn[p.n] * p.f[p.n + 1];
+  const int n = p.n;
+  size_t cur = 0;
+  auto A = [&](std::vector<size_t>& v, int i, size_t floats) { v[i] = take(cur, floats); };
+  p.encA.resize(n); p.encP.resize(n); p.decU.resize(n); p.decC.resize(n);
+  p.g_encA.resize(n); p.g_encP.resize(n); p.g_decU.resize(n); p.g_decC.resize(n);
+  size_t scratch = 0;
+  auto upd = [&](size_t b) { if (b > scratch) scratch = b; };
+  for (int i = 0; i < n; ++i) {
+    const size_t a = (size_t)B * p.Nn[i] * p.f[i + 1], q = (size_t)B * p.Nn[i + 1] * p.f[i + 1];
+    A(p.encA, i, a); A(p.g_encA, i, a); A(p.encP, i, q); A(p.g_encP, i, q);
+    upd(mvh_cheb_conv_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]));
+    upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]));
+    // decoder stage i works at level n-i-1: filters[-i-1] -> filters[-i-2]
+    const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
+    const size_t u = (size_t)B * p.Nn[lvl] * cin, c = (size_t)B * p.Nn[lvl] * cout;
+    A(p.decU, i, u); A(p.g_decU, i, u); A(p.decC, i, c); A(p.g_decC, i, c);
+    upd(mvh_cheb_conv_ws_bytes(B, p.Nn[lvl], cin, cout, d->K[i]));
+    upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[lvl], cin, cout, d->K[i]));
+  }
+  upd(mvh_cheb_conv_ws_bytes(B, p.Nn[0], p.f[1], p.f[0], d->K[n]));
+  upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[0], p.f[1], p.f[0], d->K[n]));
+  upd((size_t)B * (p.flat > p.H ? p.flat : p.H) * sizeof(float) + 256);
+  upd((size_t)B * (p.C + 2 * p.Z) * sizeof(float) + 256);
+  upd(mvh_vae_loss_ws_bytes(B));
+  p.h = take(cur, (size_t)B * p.H); p.g_h = take(cur, (size_t)B * p.H);
+  p.zy = take(cur, (size_t)B * (p.C + p.Z)); p.g_zy = take(cur, (size_t)B * (p.C + p.Z));
+  p.d1 = take(cur, (size_t)B * p.H); p.g_d1 = take(cur, (size_t)B * p.H);
+  p.d2 = take(cur, (size_t)B * p.flat); p.g_d2 = take(cur, (size_t)B * p.flat);
+  p.g_recon = take(cur, (size_t)B * p.Nn[0] * p.F0);
+  p.d_mu = take(cur, (size_t)B * p.Z); p.d_lv = take(cur, (size_t)B * p.Z); p.d_yhat = take(cur, (size_t)B * p.C);
+  p.scratch_bytes = align_up(scratch, 256);
+  p.scratch_main = cur; cur += p.scratch_bytes;
+  p.scratch_side = cur; cur += p.scratch_bytes;
+  p.total = cur + 256;
+  return MVH_OK;
+}
+
+// parameter slots, state_dict order (cheb_VAE.py:121-165)
+struct ParamIdx {
+  int n;
+  int encW(int i) const { return 2 * i; }
+  int encB(int i) const { return 2 * i + 1; }
+  int decW(int i) const { return 2 * n + 2 * i; }
+  int decB(int i) const { return 2 * n + 2 * i + 1; }  // i < n only
+  int base() const { return 4 * n + 1; }
+  int clsW() const { return base(); }       int clsB() const { return base() + 1; }
+  int zmW() const { return base() + 2; }    int zmB() const { return base() + 3; }
+  int zvW() const { return base() + 4; }    int zvB() const { return base() + 5; }
+  int encLW() const { return base() + 6; }  int encLB() const { return base() + 7; }
+  int decLW() const { return base() + 8; }  int decLB() const { return base() + 9; }
+  int dl1W() const { return base() + 10; }  int dl1B() const { return base() + 11; }
+  int dl2W() const { return base() + 12; }  int dl2B() const { return base() + 13; }
+  int count() const { return base() + 14; }
+};
+
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[64];
+  int n_ev = 0;
+  int next_ev = 0;
+};
+
+// (a kernel rather than hipMemsetAsync: memset nodes on a forked stream crashed graph instantiation)
+__global__ void __launch_bounds__(256) k_zero(float* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+static SideStream* side_for_device() {
+  static SideStream side[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& s = side[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < 64; ++i)
+      if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.n_ev = 64;
+  }
+  return &s;
+}
+
+}  // namespace mvh
+
+using namespace mvh;
+
+extern "C" size_t mvh_vae_step_ws_bytes(const mvh_vae_desc_t* desc, int32_t B) {
+  StepPlan p;
+  if (build_plan(desc, B, p)) return 0;
+  return p.total;
+}
+
+extern "C" int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc) {
+  if (!desc) return 0;
+  ParamIdx ix{desc->n_layers};
+  return ix.count();
+}
+
+#define F(off) ((float*)((char*)ws + (off)))
+#define TRY(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
+
+extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
+                               const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
+                               const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
+                               float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu,
+                               float* logvar, void* ws, size_t ws_bytes) {
+  StepPlan p;
+  TRY(build_plan(d, B, p));
+  MVH_REQUIRE(P && x && y && x_gt && loss && correct && recon && kld && rec && z && y_hat && mu && logvar,
+              "vae_forward: null tensor");
+  MVH_REQUIRE(B > 0, "vae_forward: empty batch");
+  MVH_REQUIRE(ws && ws_bytes >= p.total, "vae_forward: workspace too small (%zu < %zu)", ws_bytes, p.total);
+  const int n = p.n;
+  ParamIdx ix{n};
+  void* sm = (char*)ws + p.scratch_main;
+  const float pd = drop_u ? d->dropout_p : 0.f;
+  // dropout uniforms: [B, H | H | H | flat] per row (encoder h, classifier, dec_lin, dec_lin_2)
+  const int urow = 3 * p.H + p.flat;
+  (void)urow;
+  const float* u_enc = drop_u;
+  const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
+  const float* u_d1 = drop_u ? drop_u + (size_t)2 * B * p.H : nullptr;
+  const float* u_d2 = drop_u ? drop_u + (size_t)3 * B * p.H : nullptr;
+
+  // ---- encoder (cheb_VAE.py:261-273)
+  const float* cur = x;
+  for (int i = 0; i < n; ++i) {
+    TRY(mvh_cheb_conv_fwd(stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B, p.Nn[i],
+                          p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes));
+    TRY(mvh_pool_fwd(stream, &d->down[i], F(p.encA[i]), F(p.encP[i]), B, p.f[i + 1]));
+    cur = F(p.encP[i]);
+  }
+  TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], F(p.h), B, p.flat, p.H, MVH_ACT_RELU, u_enc, pd));
+  // ---- classifier + latent heads + reparameterisation (cheb_VAE.py:203-226)
+  TRY(mvh_vae_latent_fwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
+                         P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z));
+  // ---- decoder (cheb_VAE.py:275-292)
+  TRY(mvh_linear_fwd(stream, F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H, MVH_ACT_RELU, u_d1, pd));
+  TRY(mvh_linear_fwd(stream, F(p.d1), P[ix.dl2W()], P[ix.dl2B()], F(p.d2), B, p.H, p.flat, MVH_ACT_RELU, u_d2, pd));
+  cur = F(p.d2);
+  for (int i = 0; i < n; ++i) {
+    const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
+    TRY(mvh_pool_fwd(stream, &d->up[lvl], cur, F(p.decU[i]), B, cin));
+    TRY(mvh_cheb_conv_fwd(stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]), nullptr, B,
+                          p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes));
+    cur = F(p.decC[i]);
+  }
+  // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
+  TRY(mvh_cheb_conv_fwd(stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1], p.f[0],
+                        d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes));
+  // ---- loss (cheb_VAE.py:321-346)
+  return mvh_vae_loss_fwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld, correct, B,
+                          p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes);
+}
+
+extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P,
+                                float* const* G, const float* x, const float* y, const void* x_gt,
+                                int32_t gt_f64, const float* eps, const float* drop_u, int32_t B,
+                                float log_sigma, const void* d_loss, const float* recon, const float* y_hat,
+                                const float* mu, const float* logvar, void* ws, size_t ws_bytes,
+                                mvh_stream_t side_stream) {
+  StepPlan p;
+  TRY(build_plan(d, B, p));
+  MVH_REQUIRE(P && G && x && y && x_gt && recon && y_hat && mu && logvar, "vae_backward: null tensor");
+  MVH_REQUIRE(ws && ws_bytes >= p.total, "vae_backward: workspace too small");
+  const int n = p.n;
+  ParamIdx ix{n};
+  hipStream_t main = (hipStream_t)stream;
+  SideStream* side = side_for_device();
+  MVH_REQUIRE(side != nullptr, "vae_backward: could not create the side stream");
+  hipStream_t sstream = side_stream ? (hipStream_t)side_stream : side->stream;
+  {
+    static const char* no_side = getenv("MESHVAE_NO_SIDE");
+    if (no_side && no_side[0] == '1') sstream = main;  // debugging aid: weight gradients on the main chain
+  }
+  void* sm = (char*)ws + p.scratch_main;
+  void* ss = (char*)ws + p.scratch_side;
+  const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
+  const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
+  int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
+  // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists
+  auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
+                          const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
+                          int K, int act) -> int {
+    if (sstream != main) {
+      MVH_HIP(hipEventRecord(side->ev[ev], main));
+      MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+      ev = (ev + 1) % side->n_ev;
+    }
+    return mvh_cheb_conv_bwd((mvh_stream_t)sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N,
+                             cin, cout, K, act, ss, p.scratch_bytes);
+  };
+  auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
+                          const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
+                          int act) -> int {
+    return mvh_cheb_conv_bwd(stream, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
+                             act, sm, p.scratch_bytes);
+  };
+
+  // ---- loss
+  TRY(mvh_vae_loss_bwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, d_loss, F(p.g_recon), F(p.d_mu),
+                       F(p.d_lv), F(p.d_yhat), B, p.Nn[0] * p.F0, p.C, p.Z));
+  // ---- final conv
+  {
+    const float* xin = F(p.decC[n - 1]);
+    TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
+                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE));
+    TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
+                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE));
+  }
+  // ---- decoder stages, last to first
+  for (int i = n - 1; i >= 0; --i) {
+    const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
+    TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
+                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU));
+    TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
+                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU));
+    float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
+    TRY(mvh_pool_bwd(stream, &d->up_t[lvl], F(p.g_decU[i]), dst, B, cin));
+  }
+  // ---- dense decoder head, latent heads, dense encoder head
+  TRY(mvh_linear_bwd(stream, F(p.d1), P[ix.dl2W()], F(p.d2), F(p.g_d2), F(p.g_d1), G[ix.dl2W()], G[ix.dl2B()], B, p.H,
+                     p.flat, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  TRY(mvh_linear_bwd(stream, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), F(p.g_zy), G[ix.decLW()], G[ix.decLB()], B,
+                     p.C + p.Z, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  TRY(mvh_vae_latent_bwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar,
+                         F(p.d_yhat), F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), G[ix.clsW()], G[ix.clsB()],
+                         G[ix.zmW()], G[ix.zmB()], G[ix.zvW()], G[ix.zvB()], B, p.H, p.C, p.Z, sm, p.scratch_bytes));
+  TRY(mvh_linear_bwd(stream, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), F(p.g_encP[n - 1]), G[ix.encLW()],
+                     G[ix.encLB()], B, p.flat, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  // dec_lin_1 is never used by the forward (cheb_VAE.py:165): zero gradient
+  hipLaunchKernelGGL(k_zero, dim3(cdiv((long long)p.H * (p.C + p.Z), 256)), dim3(256), 0, main, G[ix.dl1W()],
+                     (long long)p.H * (p.C + p.Z));
+  hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, main, G[ix.dl1B()], (long long)p.H);
+  MVH_LAUNCH_CHECK();
+  // ---- encoder stages, last to first
+  for (int i = n - 1; i >= 0; --i) {
+    TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
+    const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
+    TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
+                     G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+    if (i > 0)
+      TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
+                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+  }
+  // join
+  if (sstream != main) {
+    MVH_HIP(hipEventRecord(side->ev[ev], sstream));
+    MVH_HIP(hipStreamWaitEvent(main, side->ev[ev], 0));
+    ev = (ev + 1) % side->n_ev;
+  }
+  return MVH_OK;
+}
+
+extern "C" size_t mvh_sizeof_vae_desc(void) { return sizeof(mvh_vae_desc_t); }
+extern "C" size_t mvh_sizeof_csr(void) { return sizeof(mvh_csr_t); }

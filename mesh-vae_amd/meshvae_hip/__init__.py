@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeshvae_hip.so")
+# MESHVAE_LIB lets a benchmark A/B two builds of the library in one process-per-run session
+LIB_PATH = os.environ.get("MESHVAE_LIB") or os.path.join(_HERE, "libmeshvae_hip.so")
 _lib = None
 
 
@@ -22,6 +23,20 @@ class CsrStruct(ctypes.Structure):
                 ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
                 ("rowinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p), ("ell_pairs", ctypes.c_int32),
                 ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+VAE_MAX_LAYERS = 8
+
+
+class VaeDesc(ctypes.Structure):
+    """mvh_vae_desc_t"""
+    _fields_ = [("n_layers", ctypes.c_int32), ("num_features", ctypes.c_int32), ("num_hidden", ctypes.c_int32),
+                ("num_classes", ctypes.c_int32), ("num_style", ctypes.c_int32), ("dropout_p", ctypes.c_float),
+                ("filters", ctypes.c_int32 * (VAE_MAX_LAYERS + 2)), ("K", ctypes.c_int32 * (VAE_MAX_LAYERS + 1)),
+                ("num_nodes", ctypes.c_int32 * (VAE_MAX_LAYERS + 1)),
+                ("lap", CsrStruct * (VAE_MAX_LAYERS + 1)), ("lap_t", CsrStruct * (VAE_MAX_LAYERS + 1)),
+                ("down", CsrStruct * VAE_MAX_LAYERS), ("down_t", CsrStruct * VAE_MAX_LAYERS),
+                ("up", CsrStruct * VAE_MAX_LAYERS), ("up_t", CsrStruct * VAE_MAX_LAYERS)]
 
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC = 1, 2
@@ -47,6 +62,12 @@ SIGNATURES = {
     "mvh_vae_loss_ws_bytes": (_Z, [_I]),
     "mvh_vae_loss_fwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 4 + [_P, _Z]),
     "mvh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P]),
+    "mvh_sizeof_vae_desc": (_Z, []),
+    "mvh_sizeof_csr": (_Z, []),
+    "mvh_vae_step_ws_bytes": (_Z, [ctypes.POINTER(VaeDesc), _I]),
+    "mvh_vae_param_count": (ctypes.c_int32, [ctypes.POINTER(VaeDesc)]),
+    "mvh_vae_forward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
+    "mvh_vae_backward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z, _P]),
     "mvh_vae_loss_bwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 4),
 }
 
@@ -63,6 +84,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        if handle.mvh_sizeof_csr() != ctypes.sizeof(CsrStruct) or handle.mvh_sizeof_vae_desc() != ctypes.sizeof(VaeDesc):
+            raise MeshVaeHipError("ctypes struct layout does not match libmeshvae_hip.so (stale build?)")
         _lib = handle
     return _lib
 

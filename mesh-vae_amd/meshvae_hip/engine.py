@@ -91,7 +91,8 @@ class TrainStep:
     into a static device buffer before replay.
     """
 
-    def __init__(self, net, batch, lr=1e-3, weight_decay=5e-4, use_graph=True, m_type="train", group=None):
+    def __init__(self, net, batch, lr=1e-3, weight_decay=5e-4, use_graph=True, m_type="train", group=None,
+                 native=True, n_micro=1):
         self.net, self.B, self.m_type, self.group = net, batch, m_type, group
         self.dev = next(net.parameters()).device
         self.flat = FlatParams(net)
@@ -107,6 +108,31 @@ class TrainStep:
         self.out = None
         net._eps_provider = lambda B, Z, device: self.eps      # static buffer (graph-safe)
         net._prepare()                                         # topology upload must precede any capture
+        # native=True: the whole forward+backward is one C++ launch sequence (mvh_vae_forward/backward);
+        # native=False: the per-module autograd path (what main.py drives through model.forward).
+        # n_micro > 1 splits the per-GPU batch into independent chains on their own streams: meshes
+        # are independent, so the latency-bound small-level kernels of one chain overlap the
+        # CU-filling level-0 kernels of another; gradients of the chains are summed before Adam.
+        self.n_micro = n_micro if (native and batch % max(n_micro, 1) == 0) else 1
+        self.native, self.streams, self.extra_grads = None, [], []
+        if native:
+            mb = batch // self.n_micro
+            self.native = []
+            for j in range(self.n_micro):
+                grads = None
+                if j > 0:
+                    buf = torch.zeros_like(self.flat.grad)
+                    self.extra_grads.append(buf)
+                    grads, off = [], 0
+                    for p in self.flat.params:
+                        grads.append(buf[off:off + p.numel()].view_as(p))
+                        off += p.numel()
+                # chain 0 runs on the caller's stream and forks its weight-gradient kernels to a side
+                # stream; chains >= 1 are themselves forks and keep dW inline (a fork of a fork
+                # crashes hipGraph instantiation on ROCm 7.2, tools/capture_probe.py)
+                chain = torch.cuda.Stream(self.dev) if j > 0 else None
+                self.streams.append((chain, torch.cuda.Stream(self.dev) if j == 0 else chain))
+                self.native.append(NativeStep(net, mb, grads=grads, side_stream=self.streams[j][1]))
 
     def load(self, x, x_gt, y):
         self.x.copy_(x, non_blocking=True)
@@ -114,6 +140,28 @@ class TrainStep:
         self.y.copy_(y, non_blocking=True)
 
     def _fwd_bwd(self):
+        if self.native is not None:
+            train = self.net.training and self.net.dropout.p > 0.0
+            cur = torch.cuda.current_stream(self.dev)
+            mb = self.B // self.n_micro
+            outs = []
+            for j, nat in enumerate(self.native):
+                st = self.streams[j][0]
+                sl = slice(j * mb, (j + 1) * mb)
+                if st is not None:
+                    st.wait_stream(cur)
+                with torch.cuda.stream(st if st is not None else cur):
+                    u = torch.rand(mb * nat.u_cols, device=self.dev) if train else None
+                    eps = self.eps[sl] if self.m_type == "train" else None
+                    outs.append(nat.forward_backward(self.x[sl], self.x_gt[sl], self.y[sl], eps, u))
+            for j in range(1, self.n_micro):
+                cur.wait_stream(self.streams[j][0])
+                self.flat.grad.add_(self.extra_grads[j - 1])
+            if self.n_micro > 1:   # every chain averaged over its own micro-batch
+                self.flat.grad.mul_(1.0 / self.n_micro)
+            self._micro_outs = outs
+            self.out = (outs[0][0], outs[0][1], outs[0][2]) if self.n_micro == 1 else None
+            return
         self.flat.zero_grad()
         loss, correct, recon, extra, y_hat = self.net(_Batch(self.x), self.x_gt, self.y, m_type=self.m_type)
         loss.backward()
@@ -153,4 +201,101 @@ class TrainStep:
             self._fwd_bwd()
             self.flat.all_reduce(self.group)
             self.opt.step(1.0 / self.world)
+        if self.out is None:     # micro-batched: assemble the (loss, correct, recon) triple lazily
+            o = self._micro_outs
+            self.out = (torch.stack([t[0] for t in o]).mean(), torch.stack([t[1] for t in o]).sum(),
+                        torch.cat([t[2] for t in o], 0))
         return self.out
+
+
+class NativeStep:
+    """cheb_VAE.forward + loss.backward() through mvh_vae_forward / mvh_vae_backward: every
+    kernel is enqueued from C++, activations live in one workspace, parameter gradients are
+    written straight into the module's (flat) .grad views, weight-gradient kernels run on a
+    side stream.  Semantics are those of `cheb_VAE.forward(data, x_gt, y, m_type)`."""
+
+    def __init__(self, net, batch, grads=None, side_stream=None):
+        """grads: optional list of gradient tensors (one per parameter, default = the .grad views);
+        side_stream: torch stream for the weight-gradient kernels (default: one internal per device)."""
+        import ctypes
+        from . import VaeDesc
+        self.side = side_stream
+        from .functional import _need_gpu  # noqa: F401
+        net._prepare()
+        self.net, self.B = net, batch
+        self.dev = next(net.parameters()).device
+        n = net.n_layers
+        d = VaeDesc()
+        d.n_layers, d.num_features = n, net.filters[0]
+        d.num_hidden, d.num_classes, d.num_style = net.num_hidden, net.num_class, net.z
+        d.dropout_p = float(net.dropout.p)
+        for i, v in enumerate(net.filters):
+            d.filters[i] = v
+        for i in range(n + 1):
+            d.K[i] = net.K[i]
+            d.num_nodes[i] = net.num_nodes[i]
+        for i in range(n):
+            d.lap[i], d.lap_t[i] = net._lap[i].fwd.struct, net._lap[i].bwd.struct
+            d.down[i], d.down_t[i] = net._down[i].fwd.struct, net._down[i].bwd.struct
+            d.up[i], d.up_t[i] = net._up[i].fwd.struct, net._up[i].bwd.struct
+        d.lap[n], d.lap_t[n] = net._lap_final.fwd.struct, net._lap_final.bwd.struct
+        self.desc = d
+        L = lib()
+        self.params = [p for _, p in net.named_parameters()]
+        assert len(self.params) == L.mvh_vae_param_count(ctypes.byref(d)), "unexpected parameter list"
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        PtrArr = ctypes.c_void_p * len(self.params)
+        self._P = PtrArr(*[p.data_ptr() for p in self.params])
+        self.grads = grads if grads is not None else [p.grad for p in self.params]
+        self._G = PtrArr(*[g.data_ptr() for g in self.grads])
+        self.ws_bytes = L.mvh_vae_step_ws_bytes(ctypes.byref(d), batch)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        B, C, Z = batch, net.num_class, net.z
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.recon = torch.empty(B, net.num_nodes[0], net.filters[0], **f32)
+        self.kld, self.z_ = torch.empty(B, **f32), torch.empty(B, Z, **f32)
+        self.y_hat, self.mu, self.logvar = torch.empty(B, C, **f32), torch.empty(B, Z, **f32), torch.empty(B, Z, **f32)
+        self.correct = torch.empty((), dtype=torch.int64, device=self.dev)
+        self.y_f = torch.empty(B, C, **f32)
+        self.u_cols = 3 * net.num_hidden + net.dec_lin_2.out_features
+        self._loss = {}
+        from models.cheb_VAE import LOG_SIGMA
+        self.log_sigma = LOG_SIGMA
+
+    def _refresh_pointers(self):
+        for i, p in enumerate(self.params):
+            self._P[i], self._G[i] = p.data_ptr(), self.grads[i].data_ptr()
+
+    def _outs(self, dtype):
+        if dtype not in self._loss:
+            self._loss[dtype] = (torch.empty((), dtype=dtype, device=self.dev),
+                                 torch.empty(self.B, dtype=dtype, device=self.dev))
+        return self._loss[dtype]
+
+    def forward_backward(self, x, x_gt, y, eps=None, drop_u=None, backward=True):
+        """x [B,N,F] fp32, x_gt fp32/fp64, y int64 or float one-hot [B,C].  Returns
+        (loss, correct, recon, [kld, rec, z_], y_hat) exactly like cheb_VAE.forward."""
+        import ctypes
+        L = lib()
+        x, x_gt = x.contiguous(), x_gt.contiguous()
+        self.y_f.copy_(y)
+        loss, rec = self._outs(x_gt.dtype)
+        f64 = int(x_gt.dtype == torch.float64)
+        d = ctypes.byref(self.desc)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            check(L.mvh_vae_forward(st, d, self._P, x.data_ptr(), self.y_f.data_ptr(), x_gt.data_ptr(), f64, ptr(eps),
+                                    ptr(drop_u), self.B, self.log_sigma, loss.data_ptr(), self.correct.data_ptr(),
+                                    self.recon.data_ptr(), self.kld.data_ptr(), rec.data_ptr(), self.z_.data_ptr(),
+                                    self.y_hat.data_ptr(), self.mu.data_ptr(), self.logvar.data_ptr(),
+                                    self.ws.data_ptr(), self.ws_bytes))
+            if backward:
+                check(L.mvh_vae_backward(st, d, self._P, self._G, x.data_ptr(), self.y_f.data_ptr(), x_gt.data_ptr(),
+                                         f64, ptr(eps), ptr(drop_u), self.B, self.log_sigma, None, self.recon.data_ptr(),
+                                         self.y_hat.data_ptr(), self.mu.data_ptr(), self.logvar.data_ptr(),
+                                         self.ws.data_ptr(), self.ws_bytes,
+                                         self.side.cuda_stream if self.side is not None else None))
+        return loss, self.correct, self.recon, [self.kld, rec, self.z_], self.y_hat
