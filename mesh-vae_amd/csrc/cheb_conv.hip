@@ -296,6 +296,13 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                                  const float* bias, float* out, float* tx_saved, int32_t B, int32_t N,
                                  int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
                                  size_t ws_bytes) {
+  return cheb_conv_fwd_impl((hipStream_t)stream, lap, x, W, bias, out, tx_saved, B, N, Cin, Cout, K, act, ws, ws_bytes,
+                            nullptr);
+}
+
+int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
+                            const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
+                            int act, void* ws, size_t ws_bytes, const float* prepacked) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   MVH_REQUIRE(x && W && out, "cheb_conv_fwd: null tensor");
   if ((long long)B * N == 0) return MVH_OK;
@@ -304,7 +311,8 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
-    if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled)) return rc;
+    if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled,
+                              prepacked)) return rc;
     if (handled) return MVH_OK;
   }
   float* tx = tx_saved;
@@ -331,6 +339,14 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                                  const float* tx_saved, float* dx, float* dW, float* db, int32_t B,
                                  int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
                                  size_t ws_bytes) {
+  return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, x, W, out, dout, tx_saved, dx, dW, db, B, N, Cin, Cout, K,
+                            act, ws, ws_bytes, nullptr);
+}
+
+int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
+                            const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
+                            float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
+                            size_t ws_bytes, const float* prepacked_bwd) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -370,7 +386,7 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
   {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
     bool handled = false;
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
-                              Cout, K, act, true, wpack, &handled)) return rc;
+                              Cout, K, act, true, wpack, &handled, prepacked_bwd)) return rc;
     if (handled) return MVH_OK;
   }
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2

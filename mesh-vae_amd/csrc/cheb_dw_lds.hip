@@ -59,8 +59,13 @@ __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
               const float* __restrict__ p_Qmask, const uint32_t* __restrict__ p_rowinfo,
               const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, DwDims a) {
-  static_assert(CQ % 8 == 0, "Q channels are consumed 16 at a time (4 lanes x float4)");
-  constexpr int QH = (CQ + 15) / 16;  // float4 Q registers per vertex step per lane
+  // CQ % 8 == 0: the workgroup holds all CQ channels of Q (16 per float4-per-lane register group);
+  // CQ == 4   : "Q-split" mode for P sides of <= 4 channels (cheb.0 and the final layer): the
+  //             a.CQtot channels of Q are split over CQtot/4 workgroups (one channel per lane,
+  //             one MFMA per step), so those layers still fill the chip instead of 1 WG per mesh.
+  static_assert(CQ == 4 || CQ % 8 == 0, "unsupported Q width");
+  constexpr bool SPLIT = (CQ == 4);
+  constexpr int QH = SPLIT ? 1 : (CQ + 15) / 16;  // float4 Q registers per vertex step per lane
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;
   const int NW = THREADS / 64;
@@ -71,8 +76,10 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const float* slabf = reinterpret_cast<const float*>(slab);
 
   const int NS = (a.CP + 3) >> 2;
+  const int QP = SPLIT ? a.CQtot / 4 : 1, CQT = SPLIT ? a.CQtot : CQ;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int mesh = (jj / NS) * 8 + xcd, sl = jj % NS, s0 = sl * 4;
+  const int per_mesh = NS * QP, rem = jj % per_mesh;
+  const int mesh = (jj / per_mesh) * 8 + xcd, sl = rem / QP, s0 = sl * 4, q0 = 4 * (rem % QP);
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
 
@@ -87,12 +94,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 
   // ---- Q rows in the MFMA layout: lane (b = lane>>2, i = lane&3) of step s holds
   //      Q[v][16h + 4i .. +3] / s_v  for vertex v = 16 (s NW + wave) + b
-  float4 qreg[STEPS_CT][QH];
+  float4 qreg[SPLIT ? 1 : STEPS_CT][QH];
+  float qone[SPLIT ? STEPS_CT : 1];  // split mode: one channel per lane
   float4 qsum[QH];
 #pragma unroll
   for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* Qb = p_Q + (long long)mesh * N * CQ;
-  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * N * CQ : nullptr;
+  const float* Qb = p_Q + (long long)mesh * N * CQT;
+  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * N * CQT : nullptr;
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
     const int v = 16 * (s * NW + wave) + (lane >> 2);
@@ -100,6 +108,14 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     const int vl = min(v, N - 1);
     const float deg = (float)(p_rowinfo[vl] & 255u);
     const float inv_s = valid ? (deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f) : 0.f;
+    if constexpr (SPLIT) {
+      const long long off = (long long)vl * CQT + q0 + (lane & 3);
+      float t = Qb[off];
+      if (Qm && !(Qm[off] > 0.f)) t = 0.f;
+      if (valid) qsum[0].x += t;
+      qone[s] = t * inv_s;
+      continue;
+    }
 #pragma unroll
     for (int h = 0; h < QH; ++h) {
       const int c0 = 16 * h + 4 * (lane & 3);
@@ -119,10 +135,14 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   }
 
-  float* part = p_part + (((long long)sl * a.B + mesh) * NW + wave) * (long long)(a.K + 1) * CQ * 4;
+  float* part = p_part + (((long long)sl * a.B + mesh) * NW + wave) * (long long)(a.K + 1) * CQT * 4;
   // bias gradient (plane K of the tile set, layout [q][j]): column sums of Q, written right away
-  if (a.db_mode == 1 && sl == 0) {  // lane (b, i) holds q = 16h + 4i + {0..3}
-    float* pk = part + (long long)a.K * CQ * 4;
+  if (a.db_mode == 1 && sl == 0) {  // lane (b, i) holds q = 16h + 4i + {0..3}  (split: q0 + i)
+    float* pk = part + (long long)a.K * CQT * 4;
+    if constexpr (SPLIT) {
+      const float x = sum_blocks(qsum[0].x);
+      if (lane < 4) pk[(q0 + lane) * 4] = x;
+    } else
 #pragma unroll
     for (int h = 0; h < QH; ++h) {
       float v4[4] = {qsum[h].x, qsum[h].y, qsum[h].z, qsum[h].w};
@@ -177,8 +197,8 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);  // zero in the slots past N
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (a.db_mode == 2) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
-    float* pk = part + (long long)a.K * CQ * 4;
+  if (a.db_mode == 2 && q0 == 0) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
+    float* pk = part + (long long)a.K * CQT * 4;
     float v4[4] = {psum.x, psum.y, psum.z, psum.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -226,6 +246,11 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     for (int s = 0; s < STEPS_CT; ++s) {
       const int v = 16 * (s * NW + wave) + (lane >> 2);
       const float tb = slabf[v * 4 + (lane & 3)];
+      if constexpr (SPLIT) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qone[s], tb, acc[0][0], 0, 0, 0);
+        if ((s & 7) == 7) asm volatile("" ::: "memory");
+        continue;
+      }
 #pragma unroll
       for (int h = 0; h < QH; ++h) {
         acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qreg[s][h].x, tb, acc[h][0], 0, 0, 0);
@@ -237,6 +262,14 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
     // lane (b, j), register r of acc[h][m]  =  sum over this block's vertices of
     // Q~[v][16h + 4r + m] * t~_k[v][j]; fold the 16 blocks, lanes 0..3 write the tile
+    if constexpr (SPLIT) {  // register r <-> channel q0 + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = sum_blocks(acc[0][0][r]);
+        if (lane < 4) part[((long long)k * CQT + q0 + r) * 4 + lane] = x;
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < QH; ++h)
 #pragma unroll
@@ -246,7 +279,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
           float x = acc[h][m][r];
           x = sum_blocks(x);
           const int q = 16 * h + 4 * r + m;
-          if (lane < 4 && q < CQ) part[((long long)k * CQ + q) * 4 + lane] = x;
+          if (lane < 4 && q < CQ) part[((long long)k * CQT + q) * 4 + lane] = x;
         }
   };
 
@@ -328,8 +361,8 @@ static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const 
                                 (int)lds));
     attr_bytes = lds;
   }
-  const int NS = (d.CP + 3) / 4;
-  const int grid = ((d.B + 7) / 8) * 8 * NS;
+  const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
+  const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
@@ -393,7 +426,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   const float* Q = p_is_x ? dout : x;
   const float* Qm = p_is_x ? out_mask : nullptr;
   int rc;
-  if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
+  if (NS == 1 && CQ % 4 == 0 && CQ >= 8) rc = launch_dw_cq<4>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);  // Q-split
+  else if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
   else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
   else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);

@@ -252,6 +252,38 @@ k_pack_w(const float* __restrict__ W, float* __restrict__ Wp, int K, int Cin, in
   Wp[i] = v;
 }
 
+// All convolution layers of a model in ONE launch (weights are constant within a step):
+// blockIdx.y selects the table entry.
+__global__ void __launch_bounds__(256) k_pack_all(PackTable t) {
+  const PackEntry e = t.e[blockIdx.y];
+  const int NS = (e.CO + 3) >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NS * e.K * e.CQ * 4) return;
+  const int j = i & 3, c = (i >> 2) % e.CQ, k = (i >> 2) / e.CQ % e.K, sl = (i >> 2) / e.CQ / e.K;
+  const int o = sl * 4 + j;
+  float v = 0.f;
+  if (o < e.CO)
+    v = e.bwd ? e.W[((long long)k * e.Cin + o) * e.Cout + c] : e.W[((long long)k * e.Cin + c) * e.Cout + o];
+  e.dst[i] = v;
+}
+
+int pack_entry_floats(int Cin, int Cout, int K, bool bwd) {
+  const int CQ = bwd ? Cout : Cin, CO = bwd ? Cin : Cout;
+  return ((CO + 3) / 4) * K * CQ * 4;
+}
+
+int launch_pack_all(hipStream_t st, const PackTable& t) {
+  if (t.n == 0) return MVH_OK;
+  int mx = 0;
+  for (int i = 0; i < t.n; ++i) {
+    const int nf = ((t.e[i].CO + 3) / 4) * t.e[i].K * t.e[i].CQ * 4;
+    if (nf > mx) mx = nf;
+  }
+  hipLaunchKernelGGL(k_pack_all, dim3(cdiv(mx, 256), t.n), dim3(256), 0, st, t);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
 static bool force_generic() {
   static int v = -1;
   if (v < 0) {
@@ -300,9 +332,9 @@ static int launch_cq(hipStream_t st, const LdsConvArgs& a, bool bwd, int vpt, in
 // "not eligible, use the general pipeline".
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
-                 float* wpack, bool* handled) {
+                 float* wpack, bool* handled, const float* prepacked) {
   *handled = false;
-  if (!wpack) return MVH_OK;
+  if (!wpack && !prepacked) return MVH_OK;
   if (force_generic()) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
@@ -324,13 +356,14 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   if ((size_t)n_pack * sizeof(float) > kLdsWpackBytes) return MVH_OK;
 
   LdsConvArgs a;
-  a.in = in; a.mask = mask; a.W = wpack; a.bias = bias; a.out = out;
+  a.in = in; a.mask = mask; a.W = prepacked ? prepacked : wpack; a.bias = bias; a.out = out;
   a.rowinfo = lap->rowinfo; a.ell = lap->ell;
   a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;
   a.pairs = lap->ell_pairs; a.act = act;
-  // slab-packed weights for the scalar loads of the main kernel
-  hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
-  MVH_LAUNCH_CHECK();
+  if (!prepacked) {  // slab-packed weights for the scalar loads of the main kernel
+    hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
+    MVH_LAUNCH_CHECK();
+  }
   int rc = -1;
   if (CQ == 3) rc = launch_cq<3>(st, a, bwd, vpt, threads);
   else if (CQ == 8) rc = launch_cq<8>(st, a, bwd, vpt, threads);

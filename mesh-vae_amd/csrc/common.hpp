@@ -48,7 +48,27 @@ int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, co
 // LDS-resident fused ChebConv (cheb_lds.hip); *handled == false -> caller uses the general pipeline
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
-                 float* wpack /* kLdsWpackBytes of scratch */, bool* handled);
+                 float* wpack /* kLdsWpackBytes of scratch */, bool* handled,
+                 const float* prepacked = nullptr /* slab-packed weights already built (launch_pack_all) */);
+struct PackEntry {
+  const float* W;
+  float* dst;
+  int K, Cin, Cout, CQ, CO, bwd;
+};
+struct PackTable {
+  PackEntry e[2 * (MVH_VAE_MAX_LAYERS * 2 + 1)];
+  int n;
+};
+int pack_entry_floats(int Cin, int Cout, int K, bool bwd);
+int launch_pack_all(hipStream_t st, const PackTable& t);
+// conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
+int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias,
+                       float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
+                       size_t ws_bytes, const float* prepacked);
+int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
+                       const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
+                       int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,
+                       const float* prepacked_bwd);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);

@@ -23,6 +23,7 @@ struct StepPlan {
   std::vector<size_t> encA, encP, decU, decC, g_encA, g_encP, g_decU, g_decC;
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat;
   size_t scratch_main, scratch_side, scratch_bytes;
+  std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
   size_t total;
 };
 
@@ -69,6 +70,15 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.d2 = take(cur, (size_t)B * p.flat); p.g_d2 = take(cur, (size_t)B * p.flat);
   p.g_recon = take(cur, (size_t)B * p.Nn[0] * p.F0);
   p.d_mu = take(cur, (size_t)B * p.Z); p.d_lv = take(cur, (size_t)B * p.Z); p.d_yhat = take(cur, (size_t)B * p.C);
+  p.pk_enc_f.resize(n); p.pk_enc_b.resize(n); p.pk_dec_f.resize(n + 1); p.pk_dec_b.resize(n + 1);
+  for (int i = 0; i < n; ++i) {
+    p.pk_enc_f[i] = take(cur, pack_entry_floats(p.f[i], p.f[i + 1], d->K[i], false));
+    p.pk_enc_b[i] = take(cur, pack_entry_floats(p.f[i], p.f[i + 1], d->K[i], true));
+    p.pk_dec_f[i] = take(cur, pack_entry_floats(p.f[n + 1 - i], p.f[n - i], d->K[i], false));
+    p.pk_dec_b[i] = take(cur, pack_entry_floats(p.f[n + 1 - i], p.f[n - i], d->K[i], true));
+  }
+  p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
+  p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
   p.scratch_bytes = align_up(scratch, 256);
   p.scratch_main = cur; cur += p.scratch_bytes;
   p.scratch_side = cur; cur += p.scratch_bytes;
@@ -163,11 +173,29 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   const float* u_d1 = drop_u ? drop_u + (size_t)2 * B * p.H : nullptr;
   const float* u_d2 = drop_u ? drop_u + (size_t)3 * B * p.H : nullptr;
 
+  {  // slab-packed copies of every conv weight (forward order and W^T), one launch for the step
+    PackTable t;
+    t.n = 0;
+    auto add = [&](const float* W, size_t off, int cin, int cout, int K, bool bwd) {
+      PackEntry& e = t.e[t.n++];
+      e.W = W; e.dst = F(off); e.K = K; e.Cin = cin; e.Cout = cout;
+      e.CQ = bwd ? cout : cin; e.CO = bwd ? cin : cout; e.bwd = bwd ? 1 : 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      add(P[ix.encW(i)], p.pk_enc_f[i], p.f[i], p.f[i + 1], d->K[i], false);
+      if (i > 0) add(P[ix.encW(i)], p.pk_enc_b[i], p.f[i], p.f[i + 1], d->K[i], true);
+      add(P[ix.decW(i)], p.pk_dec_f[i], p.f[n + 1 - i], p.f[n - i], d->K[i], false);
+      add(P[ix.decW(i)], p.pk_dec_b[i], p.f[n + 1 - i], p.f[n - i], d->K[i], true);
+    }
+    add(P[ix.decW(n)], p.pk_dec_f[n], p.f[1], p.f[0], d->K[n], false);
+    add(P[ix.decW(n)], p.pk_dec_b[n], p.f[1], p.f[0], d->K[n], true);
+    TRY(launch_pack_all((hipStream_t)stream, t));
+  }
   // ---- encoder (cheb_VAE.py:261-273)
   const float* cur = x;
   for (int i = 0; i < n; ++i) {
-    TRY(mvh_cheb_conv_fwd(stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B, p.Nn[i],
-                          p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes));
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B,
+                           p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i])));
     TRY(mvh_pool_fwd(stream, &d->down[i], F(p.encA[i]), F(p.encP[i]), B, p.f[i + 1]));
     cur = F(p.encP[i]);
   }
@@ -182,13 +210,13 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     TRY(mvh_pool_fwd(stream, &d->up[lvl], cur, F(p.decU[i]), B, cin));
-    TRY(mvh_cheb_conv_fwd(stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]), nullptr, B,
-                          p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes));
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
+                           nullptr, B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i])));
     cur = F(p.decC[i]);
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
-  TRY(mvh_cheb_conv_fwd(stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1], p.f[0],
-                        d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes));
+  TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
+                         p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n])));
   // ---- loss (cheb_VAE.py:321-346)
   return mvh_vae_loss_fwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld, correct, B,
                           p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes);
@@ -233,9 +261,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
-                          int act) -> int {
-    return mvh_cheb_conv_bwd(stream, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
-                             act, sm, p.scratch_bytes);
+                          int act, size_t pk) -> int {
+    return cheb_conv_bwd_impl(main, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
+                              act, sm, p.scratch_bytes, F(pk));
   };
 
   // ---- loss
@@ -247,7 +275,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
                      p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE));
     TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
-                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE));
+                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n]));
   }
   // ---- decoder stages, last to first
   for (int i = n - 1; i >= 0; --i) {
@@ -255,7 +283,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU));
     TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU));
+                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i]));
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     TRY(mvh_pool_bwd(stream, &d->up_t[lvl], F(p.g_decU[i]), dst, B, cin));
   }
@@ -282,7 +310,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                      G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
     if (i > 0)
       TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
-                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i]));
   }
   // join
   if (sstream != main) {
