@@ -58,6 +58,13 @@ typedef struct mvh_csr {
   int32_t ell_pairs;       /* ceil(max_row_nnz / 2) */
   int32_t max_row_nnz;
   int32_t flags;           /* MVH_CSR_* */
+  /* Entries only touch rows/cols < n_active (0 = unknown, treat as n_rows).  When a Laplacian is
+   * mostly empty (the final layer applies the 20-vertex edge list to 4998 vertices,
+   * cheb_VAE.py:288) `sub` may point at the same operator restricted to its leading
+   * n_active x n_active block: the convolution then splits into that small problem plus a
+   * per-vertex linear map for the isolated rows (T_k(0) = cos(k pi/2)). */
+  int32_t n_active;
+  const struct mvh_csr* sub;
 } mvh_csr_t;
 
 /* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh

@@ -274,13 +274,48 @@ static int tx_forward(hipStream_t st, const mvh_csr_t* lap, const float* x, floa
   return MVH_OK;
 }
 
+
+// ------------------------------------------------------------------ mostly-isolated Laplacians
+// When the edge list only touches the leading n_active vertices (the final layer applies the
+// 20-vertex edge list to 4998 vertices, cheb_VAE.py:288) every other vertex has L x = 0, so
+// T_k x = c_k x with c_k = T_k(0) = 1, 0, -1, 0, ... : the convolution there is the per-vertex
+// linear map x W_eff, W_eff = sum_k c_k W_k, and only the n_active x n_active block needs the
+// recurrence (run as a strided sub-problem that overwrites the leading rows).
+__device__ __forceinline__ float cheb_at_zero(int k) { return (k & 1) ? 0.f : ((k & 2) ? -1.f : 1.f); }
+
+__global__ void __launch_bounds__(256) k_weff(const float* __restrict__ W, float* __restrict__ Weff, int K, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < K; k += 2) s += cheb_at_zero(k) * W[(long long)k * n + i];
+  Weff[i] = s;
+}
+
+// dW_k = dWsub_k + c_k (S_all - dWsub_0):  S_all = sum over ALL rows of x^T dpre (a K=1 pass)
+__global__ void __launch_bounds__(256)
+k_dw_combine(float* __restrict__ dW, const float* __restrict__ dWsub, const float* __restrict__ S, int K, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * n) return;
+  const int k = i / n, e = i - k * n;
+  dW[i] = dWsub[i] + cheb_at_zero(k) * (S[e] - dWsub[e]);
+}
+
+constexpr size_t kSplitScratchBytes = 64 * 1024;
+
+static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
+  const char* e = getenv("MESHVAE_FORCE_GENERIC");
+  if (e && e[0] == '1') return false;
+  return lap->sub && lap->n_active > 0 && 4 * lap->n_active <= N && lap->sub->n_rows == lap->n_active &&
+         (size_t)(K + 2) * Cin * Cout * sizeof(float) + 1024 <= kSplitScratchBytes;
+}
+
 }  // namespace mvh
 
 using namespace mvh;
 
 extern "C" size_t mvh_cheb_conv_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
   (void)Cout;
-  return kLdsWpackBytes + align_up((size_t)(K > 1 ? K - 1 : 0) * B * N * Cin * sizeof(float), 256) + 256;
+  return kLdsWpackBytes + kSplitScratchBytes + align_up((size_t)(K > 1 ? K - 1 : 0) * B * N * Cin * sizeof(float), 256) + 256;
 }
 
 static int conv_args_ok(const mvh_csr_t* lap, int B, int N, int Cin, int Cout, int K) {
@@ -308,6 +343,16 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   if ((long long)B * N == 0) return MVH_OK;
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
+  if (!tx_saved && ws && ws_bytes >= kLdsWpackBytes + kSplitScratchBytes && split_eligible(lap, N, Cin, Cout, K)) {
+    float* weff = (float*)((char*)ws + kLdsWpackBytes);
+    hipLaunchKernelGGL(k_weff, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, W, weff, K, Cin * Cout);
+    MVH_LAUNCH_CHECK();
+    if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act)) return rc;
+    bool handled = false;
+    if (int rc = try_cheb_lds(st, lap->sub, x, nullptr, W, bias, out, B, lap->n_active, Cin, Cout, K, act, false,
+                              (float*)ws, &handled, prepacked, N, N)) return rc;
+    if (handled) return MVH_OK;  // otherwise fall through: the full path rewrites every row
+  }
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
@@ -318,7 +363,7 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   float* tx = tx_saved;
   if (!tx && K > 1) {
     MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");
-    tx = (float*)((char*)ws + kLdsWpackBytes);
+    tx = (float*)((char*)ws + kLdsWpackBytes + kSplitScratchBytes);
   }
   if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
   return launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act);
@@ -331,7 +376,7 @@ extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, 
   size_t part = align_up((size_t)dw_grid((long long)rows) * ((size_t)K * Cin + 1) * Cout * sizeof(float), 256);
   const size_t part_lds = align_up(cheb_dw_lds_ws_bytes(B, N, Cin, Cout, K), 256);
   if (part_lds > part) part = part_lds;
-  return kLdsWpackBytes + tx + g + part + 256;
+  return kLdsWpackBytes + kSplitScratchBytes + tx + g + part + 256;
 }
 
 extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
@@ -358,6 +403,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   char* p = (char*)ws;
   float* wpack = (float*)p;
   p += kLdsWpackBytes;
+  float* split = (float*)p;
+  p += kSplitScratchBytes;
   float* tx_ws = (float*)p;
   p += align_up((size_t)(K > 1 ? K - 1 : 0) * plane * sizeof(float), 256);
   float* G = (float*)p;
@@ -369,6 +416,35 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     return MVH_OK;
   }
   bool dw_done = (dW == nullptr);  // dW == NULL: dX-only call (the step engine runs dW on a side stream)
+  bool dx_done = (dx == nullptr);
+  const bool split_ok = !tx_saved && split_eligible(lap, N, Cin, Cout, K) && split_eligible(lap_t, N, Cin, Cout, K);
+  const int CC = Cin * Cout;
+  if (split_ok && !dw_done) {  // dW_k = dWsub_k + c_k (S_all - dWsub_0), see k_dw_combine
+    float* S = split + CC;                 // [CC]
+    float* dWsub = split + 2 * CC;         // [K][CC]
+    const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    const float* mask = act == MVH_ACT_RELU ? out : nullptr;
+    bool h1 = false, h2 = false;
+    if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1)) return rc;
+    if (h1)
+      if (int rc = try_cheb_dw_lds(st, lap->sub, x, dout, mask, dWsub, nullptr, B, lap->n_active, Cin, Cout, K, partial,
+                                   pbytes, &h2, N)) return rc;
+    if (h1 && h2) {
+      hipLaunchKernelGGL(k_dw_combine, dim3(cdiv(K * CC, 256)), dim3(256), 0, st, dW, dWsub, S, K, CC);
+      MVH_LAUNCH_CHECK();
+      dw_done = true;
+    }
+  }
+  if (split_ok && !dx_done) {  // dx = dpre W_eff^T everywhere, then the connected block overwrites its rows
+    float* weff = split;
+    hipLaunchKernelGGL(k_weff, dim3(cdiv(CC, 256)), dim3(256), 0, st, W, weff, K, CC);
+    MVH_LAUNCH_CHECK();
+    if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act)) return rc;
+    bool handled = false;
+    if (int rc = try_cheb_lds(st, lap_t->sub, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B,
+                              lap_t->n_active, Cin, Cout, K, act, true, wpack, &handled, prepacked_bwd, N, N)) return rc;
+    dx_done = handled;
+  }
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
@@ -382,7 +458,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     }
     if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
   }
-  if (!dx) return MVH_OK;
+  if (dx_done) return MVH_OK;
   {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
     bool handled = false;
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,

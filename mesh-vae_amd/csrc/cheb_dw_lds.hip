@@ -26,6 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct DwDims {
   int B, N, K, CP, CQtot, pairs, db_mode;  // db_mode: 0 none, 1 = column sums of Q, 2 = of P
+  int bs;                                  // rows per mesh in the P/Q/mask buffers (>= N)
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -99,8 +100,8 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   float4 qsum[QH];
 #pragma unroll
   for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* Qb = p_Q + (long long)mesh * N * CQT;
-  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * N * CQT : nullptr;
+  const float* Qb = p_Q + (long long)mesh * a.bs * CQT;
+  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
     const int v = 16 * (s * NW + wave) + (lane >> 2);
@@ -160,8 +161,8 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   float ka2[VPT];
   float4 R[VPT];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* Pb = p_P + (long long)mesh * N * a.CP;
-  const float* Pm = p_Pmask ? p_Pmask + (long long)mesh * N * a.CP : nullptr;
+  const float* Pb = p_P + (long long)mesh * a.bs * a.CP;
+  const float* Pm = p_Pmask ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
@@ -394,7 +395,7 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 // dW (+ db) through the LDS-resident kernels; *handled == false -> use the general pipeline.
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled) {
+                    bool* handled, int bstride) {
   *handled = false;
   const char* e = getenv("MESHVAE_FORCE_GENERIC");
   if (e && e[0] == '1') return MVH_OK;
@@ -421,6 +422,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   DwDims d;
   d.B = B; d.N = N; d.K = K; d.CP = CP; d.CQtot = CQ; d.pairs = lap->ell_pairs;
   d.db_mode = db ? (p_is_x ? 1 : 2) : 0;
+  d.bs = bstride > 0 ? bstride : N;
   const float* P = p_is_x ? x : dout;
   const float* Pm = p_is_x ? nullptr : out_mask;
   const float* Q = p_is_x ? dout : x;

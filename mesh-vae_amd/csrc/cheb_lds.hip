@@ -34,6 +34,7 @@ struct LdsConvArgs {
   const uint32_t* rowinfo;
   const uint32_t* ell;  // [pairs][N] pair-slot major (global)
   int B, N, K, CO, Cin, Cout, pairs, act;
+  int in_bs, out_bs;    // rows per mesh in the in/mask and out buffers (>= N: strided sub-problem)
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -45,7 +46,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
-  int B, N, K, CO, Cin, Cout, pairs, act;
+  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -84,8 +85,8 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   float ka2[VPT];
   float xs[VPT][CQ];
   float4 R[VPT];
-  const float* inb = p_in + (long long)mesh * N * CQ;
-  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * N * CQ : nullptr;
+  const float* inb = p_in + (long long)mesh * a.in_bs * CQ;
+  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * a.in_bs * CQ : nullptr;
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
@@ -213,7 +214,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     for (int j = 0; j < 4; ++j)
       if (s0 + j < a.CO) bj[j] = p_bias[s0 + j];
   }
-  float* outb = p_out + (long long)mesh * N * a.CO;
+  float* outb = p_out + (long long)mesh * a.out_bs * a.CO;
   const bool vec_store = slab_full && (a.CO % 4 == 0);
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
@@ -305,7 +306,7 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   }
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
-  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act};
+  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
@@ -332,7 +333,7 @@ static int launch_cq(hipStream_t st, const LdsConvArgs& a, bool bwd, int vpt, in
 // "not eligible, use the general pipeline".
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
-                 float* wpack, bool* handled, const float* prepacked) {
+                 float* wpack, bool* handled, const float* prepacked, int in_bstride, int out_bstride) {
   *handled = false;
   if (!wpack && !prepacked) return MVH_OK;
   if (force_generic()) return MVH_OK;
@@ -360,6 +361,8 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.rowinfo = lap->rowinfo; a.ell = lap->ell;
   a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;
   a.pairs = lap->ell_pairs; a.act = act;
+  a.in_bs = in_bstride > 0 ? in_bstride : N;
+  a.out_bs = out_bstride > 0 ? out_bstride : N;
   if (!prepacked) {  // slab-packed weights for the scalar loads of the main kernel
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
     MVH_LAUNCH_CHECK();

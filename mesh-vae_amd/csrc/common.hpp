@@ -49,7 +49,8 @@ int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, co
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled,
-                 const float* prepacked = nullptr /* slab-packed weights already built (launch_pack_all) */);
+                 const float* prepacked = nullptr /* slab-packed weights already built (launch_pack_all) */,
+                 int in_bstride = 0, int out_bstride = 0 /* rows per mesh of in/mask and out (0 = N) */);
 struct PackEntry {
   const float* W;
   float* dst;
@@ -74,6 +75,6 @@ constexpr size_t kLdsWpackBytes = 64 * 1024;
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled);
+                    bool* handled, int bstride = 0 /* rows per mesh of x/dout/out_mask (0 = N) */);
 
 }  // namespace mvh

@@ -22,7 +22,8 @@ class CsrStruct(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("nnz", ctypes.c_int32),
                 ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
                 ("rowinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p), ("ell_pairs", ctypes.c_int32),
-                ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("n_active", ctypes.c_int32), ("sub", ctypes.c_void_p)]
 
 
 VAE_MAX_LAYERS = 8

@@ -64,7 +64,15 @@ class Csr:
                                 self.col.data_ptr(), self.val.data_ptr(),
                                 self.rowinfo.data_ptr() if self.rowinfo is not None else None,
                                 self.ell.data_ptr() if self.ell is not None else None,
-                                self.ell_pairs, self.max_row_nnz, self.flags)
+                                self.ell_pairs, self.max_row_nnz, self.flags, 0, None)
+        self.n_active = int(max(int(out_idx.max()), int(in_idx.max())) + 1) if self.nnz else 0
+        self.struct.n_active = self.n_active
+        self.sub = None
+
+    def attach_sub(self, sub):
+        """`sub` = this operator restricted to its leading n_active x n_active block."""
+        self.sub = sub
+        self.struct.sub = ctypes.addressof(sub.struct)
 
     @property
     def ref(self):
@@ -97,6 +105,13 @@ def laplacian(edge_index, norm, num_nodes):
     hit = _cache.get(k)
     if hit is None:
         op = Operator(edge_index[1], edge_index[0], norm, num_nodes, num_nodes, norm.device)
+        na = op.fwd.n_active
+        if 0 < na and 4 * na <= num_nodes:
+            # mostly-isolated graph (the final layer's coarsest edge list on the finest vertices):
+            # hand the kernels the small connected problem as well
+            sub = Operator(edge_index[1], edge_index[0], norm, na, na, norm.device)
+            op.fwd.attach_sub(sub.fwd)
+            op.bwd.attach_sub(sub.bwd)
         hit = _cache[k] = (op, edge_index, norm)   # keep the tensors alive: data_ptr is the key
     return hit[0]
 
