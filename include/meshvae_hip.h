@@ -50,11 +50,12 @@ typedef struct mvh_csr {
   const float* val;      /* [nnz]      device */
   /* Optional compact form for the LDS-resident kernels (NULL / 0 = not available, the
    * general kernels are used).  rowinfo[r] = (rowptr[r] << 8) | row_length.  ell is the
-   * column list in padded ELL form, two uint16 columns per word, pair-slot major:
-   * ell[p * n_rows + r] = col(r, 2p) | col(r, 2p+1) << 16 for p < ell_pairs, with the
-   * out-of-row slots set to n_cols (an all-zero dummy row the kernels append in LDS). */
+   * column list in padded ELL form, two uint16 columns per word, vertex-major:
+   * ell[r * PW + p] = col(r, 2p) | col(r, 2p+1) << 16 with PW = 4 words per row when
+   * ell_pairs <= 4, else 8; out-of-row slots are set to n_cols (an all-zero dummy row the
+   * kernels keep in LDS).  The kernels copy it to LDS with 16-byte loads. */
   const uint32_t* rowinfo; /* [n_rows] device */
-  const uint32_t* ell;     /* [ell_pairs * n_rows] device */
+  const uint32_t* ell;     /* [n_rows * PW] device, 16-byte aligned */
   int32_t ell_pairs;       /* ceil(max_row_nnz / 2) */
   int32_t max_row_nnz;
   int32_t flags;           /* MVH_CSR_* */

@@ -84,12 +84,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
 
-  {
+  {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
-    unsigned* ew = reinterpret_cast<unsigned*>(ellv);
-    for (int i = tid; i < VS * PW; i += THREADS) {
-      const int v = i / PW, p = i - v * PW;
-      ew[i] = (v < N && p < a.pairs) ? p_ell[p * N + v] : pad;
+    const uint4 pad4 = make_uint4(pad, pad, pad, pad);
+    const uint4* src = reinterpret_cast<const uint4*>(p_ell);
+    for (int i = tid; i < VS * (PW / 4); i += THREADS) {
+      const int v = i / (PW / 4);
+      ellv[i] = (v < N) ? src[i] : pad4;
     }
   }
 

@@ -55,10 +55,11 @@ class Csr:
             info = ((rowptr[:-1] << 8) | counts).numpy().astype("uint32")      # bit pattern kept in int32
             self.rowinfo = torch.from_numpy(info.view("int32")).to(device)
             self.ell_pairs = (self.max_row_nnz + 1) // 2
-            slots = torch.full((self.n_rows, 2 * self.ell_pairs), self.n_cols, dtype=torch.int64)
+            pw = 4 if self.ell_pairs <= 4 else 8 * ((self.ell_pairs + 7) // 8)   # words per vertex (16-byte groups)
+            slots = torch.full((self.n_rows, 2 * pw), self.n_cols, dtype=torch.int64)
             pos = torch.arange(self.nnz) - rowptr[:-1][out_idx[order]]          # position inside the row
             slots[out_idx[order], pos] = col_sorted
-            packed = (slots[:, 0::2] | (slots[:, 1::2] << 16)).t().contiguous()  # [pairs, n_rows]
+            packed = (slots[:, 0::2] | (slots[:, 1::2] << 16)).contiguous()     # [n_rows, pw] vertex-major
             self.ell = torch.from_numpy(packed.numpy().astype("uint32").view("int32")).to(device)
         self.struct = CsrStruct(self.n_rows, self.n_cols, self.nnz, self.rowptr.data_ptr(),
                                 self.col.data_ptr(), self.val.data_ptr(),
