@@ -185,9 +185,20 @@ class TrainStep:
         torch.cuda.synchronize(self.dev)
 
     def _draw_eps(self):
-        if self.m_type == "train":
-            host = torch.normal(mean=0, std=1, size=(self.B, self.net.z))     # host RNG (reference :316)
-            self.eps.copy_(host, non_blocking=False)
+        """Reparameterisation noise from the HOST default generator (reference cheb_VAE.py:316), moved
+        with an asynchronous copy from a small ring of pinned buffers so the host never blocks on
+        the device (a pageable .to(device) would serialise host and GPU every step)."""
+        if self.m_type != "train":
+            return
+        if not hasattr(self, "_eps_ring"):
+            self._eps_ring = [(torch.empty(self.B, self.net.z).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._eps_i = 0
+        buf, ev = self._eps_ring[self._eps_i]
+        self._eps_i = (self._eps_i + 1) % len(self._eps_ring)
+        ev.synchronize()                                   # the copy that used this buffer 8 steps ago
+        torch.normal(mean=0, std=1, size=(self.B, self.net.z), out=buf)
+        self.eps.copy_(buf, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
 
     def step(self):
         self._draw_eps()
