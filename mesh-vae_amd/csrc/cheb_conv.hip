@@ -111,7 +111,23 @@ k_cheb_gstack(const float* __restrict__ dout, const float* __restrict__ out, con
     // plane 0 may live in a separate buffer (dx itself when K == 1)
     float* dst = (k == 0 ? g0 : G + (long long)k * rows * Cin) + r * Cin;
     const float* Wk = W + (long long)k * Cin * Cout;
-    for (int ci = 0; ci < Cin; ++ci) {
+    int ci = 0;
+    if ((Cin & 3) == 0 && ((uintptr_t)dst & 15) == 0) {  // four input channels per 16-byte store
+      for (; ci < Cin; ci += 4) {
+        float g4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float* w = Wk + (long long)(ci + t) * Cout;
+          float g = 0.f;
+#pragma unroll
+          for (int co = 0; co < COUT_T; ++co)
+            if (FULL || co < Cout) g = fmaf(dp[co], w[co], g);
+          g4[t] = g;
+        }
+        *reinterpret_cast<float4*>(dst + ci) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      }
+    }
+    for (; ci < Cin; ++ci) {
       const float* w = Wk + (long long)ci * Cout;
       float g = 0.f;
 #pragma unroll

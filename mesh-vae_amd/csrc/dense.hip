@@ -37,19 +37,35 @@ template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256)
 k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm, long long sbk,
          long long sbn, float* __restrict__ C, int M, int N, int K, const float* __restrict__ bias, int act,
-         const float* __restrict__ drop_u, float p) {
+         const float* __restrict__ drop_u, float p, const float* __restrict__ a_mask, float a_scale,
+         float* __restrict__ ones_out) {
   // one block = one 16x16 output tile; its 4 waves split K (interleaved 16-chunks) and are
-  // summed through LDS in fixed order, so the dependent-load chain per wave is K/64 long
+  // summed through LDS in fixed order, so the dependent-load chain per wave is K/64 long.
+  // a_mask (same indexing as A): A elements become (mask > 0 ? a * a_scale : 0) on load -- the
+  // relu/dropout backward mask of nn.Linear, so no separate "dpre" pass exists.
+  // ones_out: a virtual column n == N with B = 1 whose results (row sums of A^T...) go to
+  // ones_out[m]: the bias gradient comes out of the dW GEMM for free.
   __shared__ float red[3][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const int i = lane & 15, kq = lane >> 4;
+  const bool ones_col = ones_out && (n0 + i == N);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
   for (int k0 = wave * 16; k0 < K; k0 += 64) {
     float a[4], b[4];
     load_k4<A_KC>(A, sam, sak, m0 + i, M, k0 + 4 * kq, K, a);
+    if (a_mask) {
+      float mk[4];
+      load_k4<A_KC>(a_mask, sam, sak, m0 + i, M, k0 + 4 * kq, K, mk);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = mk[t] > 0.f ? a[t] * a_scale : 0.f;
+    }
     load_k4<B_KC>(Bm, sbn, sbk, n0 + i, N, k0 + 4 * kq, K, b);
+    if (ones_col) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = (k0 + 4 * kq + t < K) ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
   }
@@ -65,6 +81,14 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
     for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
   const float keep_scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
   const int n = n0 + i;
+  if (ones_col) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * kq + r;
+      if (m < M) ones_out[m] = acc[r];
+    }
+    return;
+  }
   if (n >= N) return;
   const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
@@ -78,16 +102,17 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
   }
 }
 
-int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
-                long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
-                int act, const float* drop_u, float p) {
+static int launch_gemm_ex(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
+                          long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
+                          int act, const float* drop_u, float p, const float* a_mask, float a_scale,
+                          float* ones_out) {
   if (M == 0 || N == 0) return MVH_OK;
-  const bool akc = (sak == 1) && (sam % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  const bool akc = (sak == 1) && (sam % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)a_mask % 16 == 0);
   const bool bkc = (sbk == 1) && (sbn % 4 == 0) && ((uintptr_t)Bm % 16 == 0);
-  const dim3 grid(cdiv(N, 16), cdiv(M, 16));
+  const dim3 grid(cdiv(N + (ones_out ? 1 : 0), 16), cdiv(M, 16));
 #define MVH_GEMM(AK, BK)                                                                                   \
   hipLaunchKernelGGL((k_gemm16<AK, BK>), grid, dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
-                     act, drop_u, p)
+                     act, drop_u, p, a_mask, a_scale, ones_out)
   if (akc && bkc) MVH_GEMM(true, true);
   else if (akc) MVH_GEMM(true, false);
   else if (bkc) MVH_GEMM(false, true);
@@ -95,6 +120,12 @@ int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, co
 #undef MVH_GEMM
   MVH_LAUNCH_CHECK();
   return MVH_OK;
+}
+
+int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
+                long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
+                int act, const float* drop_u, float p) {
+  return launch_gemm_ex(st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, act, drop_u, p, nullptr, 1.f, nullptr);
 }
 
 // dpre = dy masked by the forward output (relu and/or dropout zeroes) and rescaled by 1/(1-p)
@@ -296,27 +327,20 @@ extern "C" int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* 
                               const float* dy, float* dx, float* dW, float* db, int32_t B, int32_t in_f,
                               int32_t out_f, int32_t act, float p, void* ws, size_t ws_bytes) {
   MVH_REQUIRE(x && W && dy && dW, "linear_bwd: null tensor");
-  MVH_REQUIRE(ws && ws_bytes >= (size_t)B * out_f * sizeof(float), "linear_bwd: workspace too small");
   const bool masked = (act == MVH_ACT_RELU);
   MVH_REQUIRE(masked || p == 0.f, "linear_bwd: dropout without relu is not supported");
   MVH_REQUIRE(!masked || y, "linear_bwd: relu/dropout backward needs the forward output");
   hipStream_t st = (hipStream_t)stream;
-  float* dpre = (float*)ws;
-  const long long n = (long long)B * out_f;
-  if (n > 0) {
-    hipLaunchKernelGGL(k_linear_dpre, dim3(cdiv(n, 256)), dim3(256), 0, st, dy, y, dpre, n, masked ? 1 : 0,
-                       p > 0.f ? 1.f / (1.f - p) : 1.f);
-    MVH_LAUNCH_CHECK();
-  }
+  (void)ws;
+  (void)ws_bytes;
+  // dpre = masked(dy) is formed on the fly inside the GEMM A-operand loads
+  const float* mask = masked ? y : nullptr;
+  const float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
   if (dx)  // dx[b,i] = sum_o dpre[b,o] W[o,i]
-    if (int rc = launch_gemm(st, dpre, out_f, 1, W, in_f, 1, dx, B, in_f, out_f, nullptr, 0, nullptr, 0.f)) return rc;
-  // dW[o,i] = sum_b dpre[b,o] x[b,i]
-  if (int rc = launch_gemm(st, dpre, 1, out_f, x, in_f, 1, dW, out_f, in_f, B, nullptr, 0, nullptr, 0.f)) return rc;
-  if (db) {
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(out_f, 256)), dim3(256), 0, st, dpre, db, B, out_f);
-    MVH_LAUNCH_CHECK();
-  }
-  return MVH_OK;
+    if (int rc = launch_gemm_ex(st, dy, out_f, 1, W, in_f, 1, dx, B, in_f, out_f, nullptr, 0, nullptr, 0.f, mask, scale,
+                                nullptr)) return rc;
+  // dW[o,i] = sum_b dpre[b,o] x[b,i]  and  db[o] = sum_b dpre[b,o] (virtual ones column)
+  return launch_gemm_ex(st, dy, 1, out_f, x, in_f, 1, dW, out_f, in_f, B, nullptr, 0, nullptr, 0.f, mask, scale, db);
 }
 
 extern "C" int mvh_vae_latent_fwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
