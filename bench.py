@@ -101,6 +101,20 @@ def kernel_rooflines(net, B, dev):
     return res
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/): rocprofv3
+    cannot be driven from inside this process, so the counters are collected separately and read here."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for k, v in table.items():
+        if kernel_key.replace(" ", "").startswith(k.replace(" ", "")):
+            return v.get("hbm_bytes")
+    return None
+
+
 def host_cores():
     """CPUs this process may actually use: min(affinity, cgroup quota) -- the GPU box exposes
     256 hardware threads but caps the container at 16."""
@@ -227,7 +241,7 @@ def main():
             d = ks[name]
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name),
                                "avg_launch_us": d["ms"] * 1e3, "algorithmic_bytes_per_launch": d["bytes"]}
             out["kernels"] = {k: {"avg_ms": v["ms"], "algo_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
         if world == 1 and not args.no_cpu_baseline:
