@@ -66,6 +66,10 @@ typedef struct mvh_csr {
    * per-vertex linear map for the isolated rows (T_k(0) = cos(k pi/2)). */
   int32_t n_active;
   const struct mvh_csr* sub;
+  /* MVH_CSR_SELECTION operators (the one-hot downsampling matrices D, nn/pool.py): every row has
+   * exactly one entry of value 1 and no column repeats; sel_inv[c] = the row that selects column
+   * c, or -1.  Lets the step engine fold the pooling into the neighbouring convolutions. */
+  const int32_t* sel_inv; /* [n_cols] device */
 } mvh_csr_t;
 
 /* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh
@@ -73,6 +77,7 @@ typedef struct mvh_csr {
 #define MVH_CSR_NORMALIZED_LAPLACIAN 1
 /* the operator equals its transpose (same pattern, same values) */
 #define MVH_CSR_SYMMETRIC 2
+#define MVH_CSR_SELECTION 4
 
 int mvh_version(void);
 const char* mvh_last_error(void);

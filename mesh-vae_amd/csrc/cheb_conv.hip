@@ -348,12 +348,13 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                                  int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
                                  size_t ws_bytes) {
   return cheb_conv_fwd_impl((hipStream_t)stream, lap, x, W, bias, out, tx_saved, B, N, Cin, Cout, K, act, ws, ws_bytes,
-                            nullptr);
+                            nullptr, nullptr, nullptr);
 }
 
 int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                             const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
-                            int act, void* ws, size_t ws_bytes, const float* prepacked) {
+                            int act, void* ws, size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool,
+                            float* pooled) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   MVH_REQUIRE(x && W && out, "cheb_conv_fwd: null tensor");
   if ((long long)B * N == 0) return MVH_OK;
@@ -365,15 +366,24 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     MVH_LAUNCH_CHECK();
     if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act)) return rc;
     bool handled = false;
+    LdsConvOpts so;
+    so.prepacked = prepacked; so.in_bs = N; so.out_bs = N;
     if (int rc = try_cheb_lds(st, lap->sub, x, nullptr, W, bias, out, B, lap->n_active, Cin, Cout, K, act, false,
-                              (float*)ws, &handled, prepacked, N, N)) return rc;
-    if (handled) return MVH_OK;  // otherwise fall through: the full path rewrites every row
+                              (float*)ws, &handled, so)) return rc;
+    if (handled) {
+      if (pool && pooled) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
+      return MVH_OK;
+    }  // otherwise fall through: the full path rewrites every row
   }
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
-    if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled,
-                              prepacked)) return rc;
+    LdsConvOpts fo;
+    fo.prepacked = prepacked;
+    if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
+    if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled, fo))
+      return rc;
+    if (handled && pool && !fo.pool_inv) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
     if (handled) return MVH_OK;
   }
   float* tx = tx_saved;
@@ -382,7 +392,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     tx = (float*)((char*)ws + kLdsWpackBytes + kSplitScratchBytes);
   }
   if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
-  return launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act);
+  if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act)) return rc;
+  if (pool && pooled) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
+  return MVH_OK;
 }
 
 extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
@@ -457,8 +469,10 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     MVH_LAUNCH_CHECK();
     if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act)) return rc;
     bool handled = false;
+    LdsConvOpts so;
+    so.prepacked = prepacked_bwd; so.in_bs = N; so.out_bs = N;
     if (int rc = try_cheb_lds(st, lap_t->sub, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B,
-                              lap_t->n_active, Cin, Cout, K, act, true, wpack, &handled, prepacked_bwd, N, N)) return rc;
+                              lap_t->n_active, Cin, Cout, K, act, true, wpack, &handled, so)) return rc;
     dx_done = handled;
   }
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
@@ -477,8 +491,10 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   if (dx_done) return MVH_OK;
   {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
     bool handled = false;
+    LdsConvOpts bo;
+    bo.prepacked = prepacked_bwd;
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
-                              Cout, K, act, true, wpack, &handled, prepacked_bwd)) return rc;
+                              Cout, K, act, true, wpack, &handled, bo)) return rc;
     if (handled) return MVH_OK;
   }
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2

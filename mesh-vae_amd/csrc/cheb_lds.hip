@@ -35,6 +35,10 @@ struct LdsConvArgs {
   const uint32_t* ell;  // [pairs][N] pair-slot major (global)
   int B, N, K, CO, Cin, Cout, pairs, act;
   int in_bs, out_bs;    // rows per mesh in the in/mask and out buffers (>= N: strided sub-problem)
+  int mask_bs, pooled_bs;
+  const int32_t* in_map;    // optional: row v of the input is in[in_map[v]] (zero when < 0)
+  const int32_t* pool_inv;  // optional fused one-hot pooling: out row v also goes to pooled[pool_inv[v]]
+  float* pooled;
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -46,7 +50,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
-  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs;
+  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -58,7 +62,8 @@ template <int CQ, int VPT, int TCT, int PW, bool BWD>
 __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, const float* __restrict__ p_W,
            const float* __restrict__ p_bias, float* __restrict__ p_out, const uint32_t* __restrict__ p_rowinfo,
-           const uint32_t* __restrict__ p_ell, LdsConvDims a) {
+           const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_in_map,
+           const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, LdsConvDims a) {
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;  // vertex slots (> N)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -87,7 +92,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   float xs[VPT][CQ];
   float4 R[VPT];
   const float* inb = p_in + (long long)mesh * a.in_bs * CQ;
-  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * a.in_bs * CQ : nullptr;
+  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
@@ -95,12 +100,18 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     const int vl = min(v, N - 1);
     const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
-    const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rl = vl;  // input row (through the optional selection map: un-pooled gradient rows)
+    if (p_in_map) {
+      const int rr = p_in_map[vl];
+      if (rr < 0) s = 0.f;
+      rl = max(rr, 0);
+    }
     if constexpr (CQ % 4 == 0) {
 #pragma unroll
       for (int c = 0; c < CQ; c += 4) {
-        float4 t = *reinterpret_cast<const float4*>(inb + (long long)vl * CQ + c);
+        float4 t = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
         if (mkb) {
           const float4 m = *reinterpret_cast<const float4*>(mkb + (long long)vl * CQ + c);
           t.x = m.x > 0.f ? t.x : 0.f;
@@ -116,7 +127,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     } else {
 #pragma unroll
       for (int c = 0; c < CQ; ++c) {
-        float t = inb[(long long)vl * CQ + c];
+        float t = inb[(long long)rl * CQ + c];
         if (mkb && !(mkb[(long long)vl * CQ + c] > 0.f)) t = 0.f;
         xs[vi][c] = t * s;
       }
@@ -244,12 +255,18 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
     }
     float* dst = outb + (long long)v * a.CO + s0;
+    const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
+    float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
     if (vec_store) {
       *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      if (pr >= 0) *reinterpret_cast<float4*>(pdst) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (s0 + j < a.CO) dst[j] = o[j];
+        if (s0 + j < a.CO) {
+          dst[j] = o[j];
+          if (pr >= 0) pdst[j] = o[j];
+        }
     }
   }
 }
@@ -321,8 +338,9 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   }
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
-  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs};
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell, d);
+  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs};
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
+                     a.in_map, a.pool_inv, a.pooled, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -349,8 +367,9 @@ static int launch_cq(hipStream_t st, const LdsConvArgs& a, bool bwd, int vpt, in
 // "not eligible, use the general pipeline".
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
-                 float* wpack, bool* handled, const float* prepacked, int in_bstride, int out_bstride) {
+                 float* wpack, bool* handled, const LdsConvOpts& o) {
   *handled = false;
+  const float* prepacked = o.prepacked;
   if (!wpack && !prepacked) return MVH_OK;
   if (force_generic()) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
@@ -382,8 +401,11 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.rowinfo = lap->rowinfo; a.ell = lap->ell;
   a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;
   a.pairs = lap->ell_pairs; a.act = act;
-  a.in_bs = in_bstride > 0 ? in_bstride : N;
-  a.out_bs = out_bstride > 0 ? out_bstride : N;
+  a.in_bs = o.in_bs > 0 ? o.in_bs : N;
+  a.out_bs = o.out_bs > 0 ? o.out_bs : N;
+  a.mask_bs = o.mask_bs > 0 ? o.mask_bs : a.in_bs;
+  a.in_map = o.in_map; a.pool_inv = o.pool_inv; a.pooled = o.pooled; a.pooled_bs = o.pooled_bs;
+  if (o.pool_inv && (!o.pooled || ((uintptr_t)o.pooled % 16) != 0)) return MVH_OK;
   if (!prepacked) {  // slab-packed weights for the scalar loads of the main kernel
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
     MVH_LAUNCH_CHECK();

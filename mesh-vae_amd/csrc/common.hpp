@@ -46,11 +46,17 @@ int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, co
                 int act, const float* drop_u, float p);
 
 // LDS-resident fused ChebConv (cheb_lds.hip); *handled == false -> caller uses the general pipeline
+struct LdsConvOpts {
+  const float* prepacked = nullptr;   // slab-packed weights already built (launch_pack_all)
+  int in_bs = 0, out_bs = 0, mask_bs = 0;  // rows per mesh of in / out / mask buffers (0 = N; mask: = in_bs)
+  const int32_t* in_map = nullptr;    // input row v = in[in_map[v]], zero when < 0 (fused un-pooling of dout)
+  const int32_t* pool_inv = nullptr;  // fused one-hot pooling of the output into `pooled`
+  float* pooled = nullptr;
+  int pooled_bs = 0;
+};
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
-                 float* wpack /* kLdsWpackBytes of scratch */, bool* handled,
-                 const float* prepacked = nullptr /* slab-packed weights already built (launch_pack_all) */,
-                 int in_bstride = 0, int out_bstride = 0 /* rows per mesh of in/mask and out (0 = N) */);
+                 float* wpack /* kLdsWpackBytes of scratch */, bool* handled, const LdsConvOpts& o = LdsConvOpts());
 struct PackEntry {
   const float* W;
   float* dst;
@@ -65,7 +71,8 @@ int launch_pack_all(hipStream_t st, const PackTable& t);
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
 int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias,
                        float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
-                       size_t ws_bytes, const float* prepacked);
+                       size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool = nullptr,
+                       float* pooled = nullptr /* fused one-hot pooling of the output (falls back to a launch) */);
 int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
                        const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
                        int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,

@@ -194,9 +194,10 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   // ---- encoder (cheb_VAE.py:261-273)
   const float* cur = x;
   for (int i = 0; i < n; ++i) {
+    // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B,
-                           p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i])));
-    TRY(mvh_pool_fwd(stream, &d->down[i], F(p.encA[i]), F(p.encP[i]), B, p.f[i + 1]));
+                           p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
+                           &d->down[i], F(p.encP[i])));
     cur = F(p.encP[i]);
   }
   TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], F(p.h), B, p.flat, p.H, MVH_ACT_RELU, u_enc, pd));

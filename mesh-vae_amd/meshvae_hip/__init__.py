@@ -23,7 +23,7 @@ class CsrStruct(ctypes.Structure):
                 ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
                 ("rowinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p), ("ell_pairs", ctypes.c_int32),
                 ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("n_active", ctypes.c_int32), ("sub", ctypes.c_void_p)]
+                ("n_active", ctypes.c_int32), ("sub", ctypes.c_void_p), ("sel_inv", ctypes.c_void_p)]
 
 
 VAE_MAX_LAYERS = 8
@@ -40,7 +40,7 @@ class VaeDesc(ctypes.Structure):
                 ("up", CsrStruct * VAE_MAX_LAYERS), ("up_t", CsrStruct * VAE_MAX_LAYERS)]
 
 
-CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC = 1, 2
+CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION = 1, 2, 4
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 

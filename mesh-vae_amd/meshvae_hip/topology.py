@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from . import CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CsrStruct
+from . import CSR_NORMALIZED_LAPLACIAN, CSR_SELECTION, CSR_SYMMETRIC, CsrStruct
 
 
 class Csr:
@@ -65,7 +65,17 @@ class Csr:
                                 self.col.data_ptr(), self.val.data_ptr(),
                                 self.rowinfo.data_ptr() if self.rowinfo is not None else None,
                                 self.ell.data_ptr() if self.ell is not None else None,
-                                self.ell_pairs, self.max_row_nnz, self.flags, 0, None)
+                                self.ell_pairs, self.max_row_nnz, self.flags, 0, None, None)
+        # one-hot selection (downsampling D): one unit entry per row, no repeated column
+        self.sel_inv = None
+        if self.nnz == self.n_rows and self.nnz > 0 and bool((counts == 1).all()) and bool((val_sorted == 1.0).all()) \
+                and int(torch.unique(col_sorted).numel()) == self.nnz:
+            inv = torch.full((self.n_cols,), -1, dtype=torch.int32)
+            inv[col_sorted] = out_idx[order].to(torch.int32)
+            self.sel_inv = inv.to(device)
+            self.flags |= CSR_SELECTION
+            self.struct.flags = self.flags
+            self.struct.sel_inv = self.sel_inv.data_ptr()
         self.n_active = int(max(int(out_idx.max()), int(in_idx.max())) + 1) if self.nnz else 0
         self.struct.n_active = self.n_active
         self.sub = None
