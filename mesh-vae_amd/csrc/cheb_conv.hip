@@ -413,13 +413,13 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                                  int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
                                  size_t ws_bytes) {
   return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, x, W, out, dout, tx_saved, dx, dW, db, B, N, Cin, Cout, K,
-                            act, ws, ws_bytes, nullptr);
+                            act, ws, ws_bytes, nullptr, nullptr, nullptr);
 }
 
 int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
                             const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
-                            size_t ws_bytes, const float* prepacked_bwd) {
+                            size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -441,6 +441,37 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   if (rows == 0) {
     if (dW) MVH_HIP(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
     if (db) MVH_HIP(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st));
+    return MVH_OK;
+  }
+  if (dout_pool) {
+    // `dout` is the gradient of the POOLED output: the un-pooling (a scatter into zeros in the
+    // reference's autograd) is folded into the loads of the LDS kernels; all or nothing.
+    MVH_REQUIRE(fused_ok != nullptr, "cheb_conv_bwd: fused_ok required with dout_pool");
+    *fused_ok = false;
+    if (tx_saved || !dout_pool->sel_inv) return MVH_OK;
+    const float* mask = act == MVH_ACT_RELU ? out : nullptr;
+    const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    bool ok_dw = (dW == nullptr), ok_dx = (dx == nullptr);
+    LdsConvOpts bo;
+    bo.prepacked = prepacked_bwd; bo.in_map = dout_pool->sel_inv; bo.in_bs = dout_pool->n_rows; bo.mask_bs = N;
+    bo.dry_run = true;
+    if (!ok_dw)
+      if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &ok_dw, 0,
+                                   dout_pool->sel_inv, dout_pool->n_rows, true)) return rc;
+    if (!ok_dx)
+      if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &ok_dx, bo))
+        return rc;
+    if (!ok_dw || !ok_dx) return MVH_OK;  // caller un-pools explicitly and calls again without dout_pool
+    bool h = false;
+    if (dW)
+      if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &h, 0,
+                                   dout_pool->sel_inv, dout_pool->n_rows, false)) return rc;
+    if (dx) {
+      bo.dry_run = false;
+      if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &h, bo))
+        return rc;
+    }
+    *fused_ok = true;
     return MVH_OK;
   }
   bool dw_done = (dW == nullptr);  // dW == NULL: dX-only call (the step engine runs dW on a side stream)

@@ -27,6 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct DwDims {
   int B, N, K, CP, CQtot, pairs, db_mode;  // db_mode: 0 none, 1 = column sums of Q, 2 = of P
   int bs;                                  // rows per mesh in the P/Q/mask buffers (>= N)
+  int map_side, map_bs;                    // fused un-pooling of dout: 1 = P rows, 2 = Q rows come through p_map
+                                           // from a compact buffer of map_bs rows per mesh (masks stay full-size)
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -59,7 +61,8 @@ template <int CQ, int VPT, int TCT, int PW>
 __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
               const float* __restrict__ p_Qmask, const uint32_t* __restrict__ p_rowinfo,
-              const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, DwDims a) {
+              const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, const int32_t* __restrict__ p_map,
+              DwDims a) {
   // CQ % 8 == 0: the workgroup holds all CQ channels of Q (16 per float4-per-lane register group);
   // CQ == 4   : "Q-split" mode for P sides of <= 4 channels (cheb.0 and the final layer): the
   //             a.CQtot channels of Q are split over CQtot/4 workgroups (one channel per lane,
@@ -101,7 +104,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   float4 qsum[QH];
 #pragma unroll
   for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* Qb = p_Q + (long long)mesh * a.bs * CQT;
+  const float* Qb = p_Q + (long long)mesh * (a.map_side == 2 ? a.map_bs : a.bs) * CQT;
   const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
@@ -109,11 +112,18 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     const bool valid = v < N;
     const int vl = min(v, N - 1);
     const float deg = (float)(p_rowinfo[vl] & 255u);
-    const float inv_s = valid ? (deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f) : 0.f;
+    float inv_s = valid ? (deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f) : 0.f;
+    int ql = vl;  // Q row (through the selection map when Q = un-pooled dout)
+    bool qhave = true;
+    if (a.map_side == 2) {
+      const int rr = p_map[vl];
+      qhave = rr >= 0;
+      ql = max(rr, 0);
+    }
     if constexpr (SPLIT) {
-      const long long off = (long long)vl * CQT + q0 + (lane & 3);
-      float t = Qb[off];
-      if (Qm && !(Qm[off] > 0.f)) t = 0.f;
+      const long long off = (long long)ql * CQT + q0 + (lane & 3);
+      float t = qhave ? Qb[off] : 0.f;
+      if (Qm && !(Qm[(long long)vl * CQT + q0 + (lane & 3)] > 0.f)) t = 0.f;
       if (valid) qsum[0].x += t;
       qone[s] = t * inv_s;
       continue;
@@ -123,7 +133,8 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       const int c0 = 16 * h + 4 * (lane & 3);
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c0 < CQ) {
-        t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
+        t = *reinterpret_cast<const float4*>(Qb + (long long)ql * CQ + c0);
+        if (!qhave) t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Qm) {
           const float4 m = *reinterpret_cast<const float4*>(Qm + (long long)vl * CQ + c0);
           t.x = m.x > 0.f ? t.x : 0.f;
@@ -162,7 +173,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   float ka2[VPT];
   float4 R[VPT];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* Pb = p_P + (long long)mesh * a.bs * a.CP;
+  const float* Pb = p_P + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
   const float* Pm = p_Pmask ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
 #pragma unroll
@@ -174,8 +185,16 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
+    int pl = vl;
+    bool phave = true;
+    if (a.map_side == 1) {
+      const int rr = p_map[vl];
+      phave = rr >= 0;
+      pl = max(rr, 0);
+    }
     if (slab_full) {
-      float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)vl * a.CP + s0);
+      float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
+      if (!phave) tv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (Pm) {
         const float4 m = *reinterpret_cast<const float4*>(Pm + (long long)vl * a.CP + s0);
         tv.x = m.x > 0.f ? tv.x : 0.f;
@@ -188,7 +207,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (s0 + j < a.CP) {
-          float x = Pb[(long long)vl * a.CP + s0 + j];
+          float x = phave ? Pb[(long long)pl * a.CP + s0 + j] : 0.f;
           if (Pm && !(Pm[(long long)vl * a.CP + s0 + j] > 0.f)) x = 0.f;
           t[j] = x;
         }
@@ -354,7 +373,7 @@ k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NS, int K
 
 template <int CQ, int VPT, int TCT, int PW>
 static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
-                         const mvh_csr_t* lap, float* part, const DwDims& d, int threads) {
+                         const mvh_csr_t* lap, float* part, const DwDims& d, int threads, const int32_t* map) {
   auto kern = k_cheb_dw_lds<CQ, VPT, TCT, PW>;
   const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
   static size_t attr_bytes = 0;
@@ -365,18 +384,18 @@ static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const 
   }
   const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
   const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, d);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
 
 template <int CQ>
 static int launch_dw_cq(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
-                        const mvh_csr_t* lap, float* part, const DwDims& d, int vpt, int threads) {
+                        const mvh_csr_t* lap, float* part, const DwDims& d, int vpt, int threads, const int32_t* map) {
   const bool pw8 = d.pairs > 4;
 #define MVH_DW(V, T)                                                                                         \
-  return pw8 ? launch_dw_one<CQ, V, T, 8>(st, P, Pm, Q, Qm, lap, part, d, threads)                           \
-             : launch_dw_one<CQ, V, T, 4>(st, P, Pm, Q, Qm, lap, part, d, threads)
+  return pw8 ? launch_dw_one<CQ, V, T, 8>(st, P, Pm, Q, Qm, lap, part, d, threads, map)                      \
+             : launch_dw_one<CQ, V, T, 4>(st, P, Pm, Q, Qm, lap, part, d, threads, map)
   if (vpt == 1) { MVH_DW(1, 0); }
   if (vpt == 2) { MVH_DW(2, 0); }
   if constexpr (CQ <= 16) {
@@ -396,7 +415,7 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 // dW (+ db) through the LDS-resident kernels; *handled == false -> use the general pipeline.
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled, int bstride) {
+                    bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run) {
   *handled = false;
   const char* e = getenv("MESHVAE_FORCE_GENERIC");
   if (e && e[0] == '1') return MVH_OK;
@@ -420,19 +439,25 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   const size_t need_bytes = (size_t)B * NS * NW * (K + 1) * CQ * 4 * sizeof(float);
   if (!part || part_bytes < need_bytes) return MVH_OK;
 
+  if (dry_run) {
+    *handled = true;
+    return MVH_OK;
+  }
   DwDims d;
   d.B = B; d.N = N; d.K = K; d.CP = CP; d.CQtot = CQ; d.pairs = lap->ell_pairs;
   d.db_mode = db ? (p_is_x ? 1 : 2) : 0;
   d.bs = bstride > 0 ? bstride : N;
+  d.map_side = dout_map ? (p_is_x ? 2 : 1) : 0;  // dout is Q when x runs the recurrence, else P
+  d.map_bs = dout_rows;
   const float* P = p_is_x ? x : dout;
   const float* Pm = p_is_x ? nullptr : out_mask;
   const float* Q = p_is_x ? dout : x;
   const float* Qm = p_is_x ? out_mask : nullptr;
   int rc;
-  if (NS == 1 && CQ % 4 == 0 && CQ >= 8) rc = launch_dw_cq<4>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);  // Q-split
-  else if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
-  else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
-  else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads);
+  if (NS == 1 && CQ % 4 == 0 && CQ >= 8) rc = launch_dw_cq<4>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);  // Q-split
+  else if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
+  else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
+  else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
   if (rc) return rc;
   const int n_out = NS * (K + 1) * CQ * 4;

@@ -406,6 +406,10 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.mask_bs = o.mask_bs > 0 ? o.mask_bs : a.in_bs;
   a.in_map = o.in_map; a.pool_inv = o.pool_inv; a.pooled = o.pooled; a.pooled_bs = o.pooled_bs;
   if (o.pool_inv && (!o.pooled || ((uintptr_t)o.pooled % 16) != 0)) return MVH_OK;
+  if (o.dry_run) {  // eligibility probe only: nothing is launched
+    *handled = true;
+    return MVH_OK;
+  }
   if (!prepacked) {  // slab-packed weights for the scalar loads of the main kernel
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
     MVH_LAUNCH_CHECK();

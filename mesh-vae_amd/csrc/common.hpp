@@ -53,6 +53,7 @@ struct LdsConvOpts {
   const int32_t* pool_inv = nullptr;  // fused one-hot pooling of the output into `pooled`
   float* pooled = nullptr;
   int pooled_bs = 0;
+  bool dry_run = false;               // only report eligibility through *handled
 };
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
@@ -76,12 +77,17 @@ int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, con
 int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
                        const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
                        int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,
-                       const float* prepacked_bwd);
+                       const float* prepacked_bwd, const mvh_csr_t* dout_pool = nullptr /* dout is the gradient of
+                       the POOLED output [B, dout_pool->n_rows, Cout]; un-pooling is fused into the loads */,
+                       bool* fused_ok = nullptr /* set false (nothing launched) when that fusion is not available */);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled, int bstride = 0 /* rows per mesh of x/dout/out_mask (0 = N) */);
+                    bool* handled, int bstride = 0 /* rows per mesh of x/dout/out_mask (0 = N) */,
+                    const int32_t* dout_map = nullptr, int dout_rows = 0 /* dout row v = dout[map[v]] (zero if < 0),
+                                                                            compact buffer of dout_rows per mesh */,
+                    bool dry_run = false);
 
 }  // namespace mvh

@@ -303,13 +303,30 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                      (long long)p.H * (p.C + p.Z));
   hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, main, G[ix.dl1B()], (long long)p.H);
   MVH_LAUNCH_CHECK();
-  // ---- encoder stages, last to first
+  // ---- encoder stages, last to first.  g_encP[i] is the gradient of the POOLED conv output; the
+  // one-hot un-pooling is folded into the loads of the dW / dX kernels (no scatter launch, no
+  // zero-filled [B, N_i, C] gradient tensor); if a layer is not eligible it is un-pooled explicitly.
   for (int i = n - 1; i >= 0; --i) {
-    TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
-    TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
-                     G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+    bool ok_dw = false, ok_dx = (i == 0);
+    if (sstream != main) {
+      MVH_HIP(hipEventRecord(side->ev[ev], main));
+      MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+      ev = (ev + 1) % side->n_ev;
+    }
+    TRY(cheb_conv_bwd_impl(sstream, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
+                           nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, ss,
+                           p.scratch_bytes, nullptr, &d->down[i], &ok_dw));
     if (i > 0)
+      TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
+                             F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
+                             sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx));
+    if (ok_dw && ok_dx) continue;
+    TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
+    if (!ok_dw)
+      TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
+                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+    if (!ok_dx)
       TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
                        p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i]));
   }
