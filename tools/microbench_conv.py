@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--dwonly", action="store_true", help="backward without dX (weight/bias gradient kernels only)")
     ap.add_argument("--relu", type=int, default=1)
     args = ap.parse_args()
 
@@ -54,10 +55,10 @@ def main():
 
     def bwd():
         check(L.mvh_cheb_conv_bwd(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                  dout.data_ptr(), None, dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                  dout.data_ptr(), None, None if args.dwonly else dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
                                   B, N, Cin, Cout, K, args.relu, ws.data_ptr(), wsb))
 
-    fn = bwd if args.bwd else fwd
+    fn = bwd if (args.bwd or args.dwonly) else fwd
     fwd()
     for _ in range(3):
         fn()
@@ -69,7 +70,7 @@ def main():
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / args.iters
-    print(f"level {args.level} N={N} {Cin}->{Cout} K={K} B={B} {'bwd' if args.bwd else 'fwd'}: {us:.1f} us/call")
+    print(f"level {args.level} N={N} {Cin}->{Cout} K={K} B={B} {'dW' if args.dwonly else ('bwd' if args.bwd else 'fwd')}: {us:.1f} us/call")
 
 
 if __name__ == "__main__":
