@@ -318,6 +318,15 @@ k_dw_combine(float* __restrict__ dW, const float* __restrict__ dWsub, const floa
 
 constexpr size_t kSplitScratchBytes = 64 * 1024;
 
+// fallback producer of the ReLU sign bytes (the LDS kernel writes them in its epilogue)
+__global__ void __launch_bounds__(256)
+k_relu_bits(const float* __restrict__ out, uint8_t* __restrict__ bits, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 o = reinterpret_cast<const float4*>(out)[i];
+  bits[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+}
+
 static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   const char* e = getenv("MESHVAE_FORCE_GENERIC");
   if (e && e[0] == '1') return false;
@@ -354,8 +363,17 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
 int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                             const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
                             int act, void* ws, size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool,
-                            float* pooled) {
+                            float* pooled, uint8_t* bits_out) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
+  MVH_REQUIRE(!bits_out || Cout % 4 == 0, "cheb_conv_fwd: sign bytes need Cout %% 4 == 0");
+  auto finish = [&](bool bits_done) -> int {  // pooling / sign bytes the main kernel did not produce itself
+    if (bits_out && !bits_done) {
+      const long long n = (long long)B * N * (Cout / 4);
+      hipLaunchKernelGGL(k_relu_bits, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, bits_out, n);
+      MVH_LAUNCH_CHECK();
+    }
+    return MVH_OK;
+  };
   MVH_REQUIRE(x && W && out, "cheb_conv_fwd: null tensor");
   if ((long long)B * N == 0) return MVH_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -371,8 +389,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     if (int rc = try_cheb_lds(st, lap->sub, x, nullptr, W, bias, out, B, lap->n_active, Cin, Cout, K, act, false,
                               (float*)ws, &handled, so)) return rc;
     if (handled) {
-      if (pool && pooled) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
-      return MVH_OK;
+      if (pool && pooled)
+        if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
+      return finish(false);
     }  // otherwise fall through: the full path rewrites every row
   }
   if (!tx_saved) {  // fused path: one launch, no T_k stack
@@ -381,10 +400,12 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     LdsConvOpts fo;
     fo.prepacked = prepacked;
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
+    fo.bits_out = bits_out;
     if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled, fo))
       return rc;
-    if (handled && pool && !fo.pool_inv) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
-    if (handled) return MVH_OK;
+    if (handled && pool && !fo.pool_inv)
+      if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
+    if (handled) return finish(true);
   }
   float* tx = tx_saved;
   if (!tx && K > 1) {
@@ -393,8 +414,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   }
   if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
   if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act)) return rc;
-  if (pool && pooled) return launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true);
-  return MVH_OK;
+  if (pool && pooled)
+    if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
+  return finish(false);
 }
 
 extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
@@ -419,7 +441,8 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
 int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
                             const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
-                            size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok) {
+                            size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok,
+                            const uint8_t* out_bits) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -428,6 +451,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
+  if (act != MVH_ACT_RELU || Cout % 4 != 0) out_bits = nullptr;
   char* p = (char*)ws;
   float* wpack = (float*)p;
   p += kLdsWpackBytes;
@@ -454,10 +478,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     bool ok_dw = (dW == nullptr), ok_dx = (dx == nullptr);
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd; bo.in_map = dout_pool->sel_inv; bo.in_bs = dout_pool->n_rows; bo.mask_bs = N;
+    bo.mask_bits = out_bits;
     bo.dry_run = true;
     if (!ok_dw)
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &ok_dw, 0,
-                                   dout_pool->sel_inv, dout_pool->n_rows, true)) return rc;
+                                   dout_pool->sel_inv, dout_pool->n_rows, true, out_bits)) return rc;
     if (!ok_dx)
       if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &ok_dx, bo))
         return rc;
@@ -465,7 +490,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     bool h = false;
     if (dW)
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &h, 0,
-                                   dout_pool->sel_inv, dout_pool->n_rows, false)) return rc;
+                                   dout_pool->sel_inv, dout_pool->n_rows, false, out_bits)) return rc;
     if (dx) {
       bo.dry_run = false;
       if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &h, bo))
@@ -509,7 +534,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
-                                 partial, pbytes, &dw_done)) return rc;
+                                 partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits)) return rc;
   }
   if (!dw_done) {
     const float* tx = tx_saved;
@@ -524,6 +549,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     bool handled = false;
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd;
+    bo.mask_bits = out_bits;
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
                               Cout, K, act, true, wpack, &handled, bo)) return rc;
     if (handled) return MVH_OK;

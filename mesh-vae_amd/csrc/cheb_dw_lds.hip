@@ -29,6 +29,7 @@ struct DwDims {
   int bs;                                  // rows per mesh in the P/Q/mask buffers (>= N)
   int map_side, map_bs;                    // fused un-pooling of dout: 1 = P rows, 2 = Q rows come through p_map
                                            // from a compact buffer of map_bs rows per mesh (masks stay full-size)
+  int mask_bits;                           // the mask pointer holds ReLU sign bytes (one per vertex and 4 channels)
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -105,7 +106,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
   for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Qb = p_Q + (long long)mesh * (a.map_side == 2 ? a.map_bs : a.bs) * CQT;
-  const float* Qm = p_Qmask ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
+  const float* Qm = (p_Qmask && !a.mask_bits) ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
+  const uint8_t* Qbits = (p_Qmask && a.mask_bits)
+                             ? reinterpret_cast<const uint8_t*>(p_Qmask) + (long long)mesh * a.bs * (CQT / 4) : nullptr;
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
     const int v = 16 * (s * NW + wave) + (lane >> 2);
@@ -124,6 +127,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       const long long off = (long long)ql * CQT + q0 + (lane & 3);
       float t = qhave ? Qb[off] : 0.f;
       if (Qm && !(Qm[(long long)vl * CQT + q0 + (lane & 3)] > 0.f)) t = 0.f;
+      if (Qbits && !((Qbits[vl * (CQT / 4) + (q0 >> 2)] >> (lane & 3)) & 1)) t = 0.f;
       if (valid) qsum[0].x += t;
       qone[s] = t * inv_s;
       continue;
@@ -141,6 +145,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
           t.y = m.y > 0.f ? t.y : 0.f;
           t.z = m.z > 0.f ? t.z : 0.f;
           t.w = m.w > 0.f ? t.w : 0.f;
+        }
+        if (Qbits) {
+          const uint32_t m = Qbits[vl * (CQ / 4) + (c0 >> 2)];
+          t.x = (m & 1u) ? t.x : 0.f;
+          t.y = (m & 2u) ? t.y : 0.f;
+          t.z = (m & 4u) ? t.z : 0.f;
+          t.w = (m & 8u) ? t.w : 0.f;
         }
       }
       if (valid) add4f(qsum[h], t);
@@ -174,7 +185,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   float4 R[VPT];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Pb = p_P + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
-  const float* Pm = p_Pmask ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
+  const float* Pm = (p_Pmask && !a.mask_bits) ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
+  const uint8_t* Pbits = (p_Pmask && a.mask_bits)
+                             ? reinterpret_cast<const uint8_t*>(p_Pmask) + (long long)mesh * a.bs * (a.CP >> 2) : nullptr;
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
@@ -201,6 +214,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         tv.y = m.y > 0.f ? tv.y : 0.f;
         tv.z = m.z > 0.f ? tv.z : 0.f;
         tv.w = m.w > 0.f ? tv.w : 0.f;
+      }
+      if (Pbits) {  // CP % 4 == 0 (host check)
+        const uint32_t m = Pbits[vl * (a.CP >> 2) + sl];
+        tv.x = (m & 1u) ? tv.x : 0.f;
+        tv.y = (m & 2u) ? tv.y : 0.f;
+        tv.z = (m & 4u) ? tv.z : 0.f;
+        tv.w = (m & 8u) ? tv.w : 0.f;
       }
       t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
     } else {
@@ -415,7 +435,8 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 // dW (+ db) through the LDS-resident kernels; *handled == false -> use the general pipeline.
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run) {
+                    bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
+                    const uint8_t* out_bits) {
   *handled = false;
   const char* e = getenv("MESHVAE_FORCE_GENERIC");
   if (e && e[0] == '1') return MVH_OK;
@@ -439,11 +460,14 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   const size_t need_bytes = (size_t)B * NS * NW * (K + 1) * CQ * 4 * sizeof(float);
   if (!part || part_bytes < need_bytes) return MVH_OK;
 
+  if (out_bits && Cout % 4 != 0) out_bits = nullptr;  // sign bytes cover whole 4-channel groups only
   if (dry_run) {
     *handled = true;
     return MVH_OK;
   }
   DwDims d;
+  d.mask_bits = out_bits ? 1 : 0;
+  if (out_bits) out_mask = reinterpret_cast<const float*>(out_bits);
   d.B = B; d.N = N; d.K = K; d.CP = CP; d.CQtot = CQ; d.pairs = lap->ell_pairs;
   d.db_mode = db ? (p_is_x ? 1 : 2) : 0;
   d.bs = bstride > 0 ? bstride : N;

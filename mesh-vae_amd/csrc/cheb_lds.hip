@@ -36,6 +36,8 @@ struct LdsConvArgs {
   int B, N, K, CO, Cin, Cout, pairs, act;
   int in_bs, out_bs;    // rows per mesh in the in/mask and out buffers (>= N: strided sub-problem)
   int mask_bs, pooled_bs;
+  int mask_bits;            // mask points at ReLU sign bytes (one per vertex and 4 channels) instead of floats
+  uint8_t* bits_out;        // forward: also store the ReLU sign bytes of the output
   const int32_t* in_map;    // optional: row v of the input is in[in_map[v]] (zero when < 0)
   const int32_t* pool_inv;  // optional fused one-hot pooling: out row v also goes to pooled[pool_inv[v]]
   float* pooled;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
-  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs;
+  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, const float* __restrict__ p_W,
            const float* __restrict__ p_bias, float* __restrict__ p_out, const uint32_t* __restrict__ p_rowinfo,
            const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_in_map,
-           const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, LdsConvDims a) {
+           const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, uint8_t* __restrict__ p_bits_out,
+           LdsConvDims a) {
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;  // vertex slots (> N)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -92,7 +95,10 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   float xs[VPT][CQ];
   float4 R[VPT];
   const float* inb = p_in + (long long)mesh * a.in_bs * CQ;
-  const float* mkb = (BWD && p_mask) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
+  const bool use_bits = BWD && p_mask && a.mask_bits && (CQ % 4 == 0);
+  const float* mkb = (BWD && p_mask && !use_bits) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
+  // ReLU sign bytes written by the forward kernel: CQ/4 bytes per vertex, bit j of byte c/4 = out[v][c+j] > 0
+  const uint8_t* mbits = reinterpret_cast<const uint8_t*>(p_mask) + (long long)mesh * a.mask_bs * (CQ / 4);
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
@@ -109,9 +115,33 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       rl = max(rr, 0);
     }
     if constexpr (CQ % 4 == 0) {
+      uint32_t mw[(CQ + 15) / 16];
+#pragma unroll
+      for (int h = 0; h < (CQ + 15) / 16; ++h) mw[h] = 0xffffffffu;
+      if (use_bits) {
+        if constexpr (CQ % 16 == 0) {
+#pragma unroll
+          for (int h = 0; h < CQ / 16; ++h) mw[h] = reinterpret_cast<const uint32_t*>(mbits)[vl * (CQ / 16) + h];
+        } else if constexpr (CQ == 8) {
+          mw[0] = reinterpret_cast<const uint16_t*>(mbits)[vl];
+        } else {
+#pragma unroll
+          for (int c = 0; c < CQ; c += 4) {
+            if (c % 16 == 0) mw[c / 16] = 0;
+            mw[c / 16] |= (uint32_t)mbits[vl * (CQ / 4) + c / 4] << (2 * (c % 16));
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CQ; c += 4) {
         float4 t = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
+        if (use_bits) {
+          const uint32_t m = mw[c / 16] >> (2 * (c % 16));
+          t.x = (m & 1u) ? t.x : 0.f;
+          t.y = (m & 2u) ? t.y : 0.f;
+          t.z = (m & 4u) ? t.z : 0.f;
+          t.w = (m & 8u) ? t.w : 0.f;
+        }
         if (mkb) {
           const float4 m = *reinterpret_cast<const float4*>(mkb + (long long)vl * CQ + c);
           t.x = m.x > 0.f ? t.x : 0.f;
@@ -254,6 +284,9 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
     }
+    if (!BWD && p_bits_out)  // CO % 4 == 0 (checked on the host): one sign byte per (vertex, slab)
+      p_bits_out[((long long)mesh * a.out_bs + v) * (a.CO >> 2) + (s0 >> 2)] =
+          (uint8_t)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
     float* dst = outb + (long long)v * a.CO + s0;
     const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
@@ -338,9 +371,10 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   }
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
-  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs};
+  LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
+                a.mask_bits};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
-                     a.in_map, a.pool_inv, a.pooled, d);
+                     a.in_map, a.pool_inv, a.pooled, a.bits_out, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -397,6 +431,16 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   if ((size_t)n_pack * sizeof(float) > kLdsWpackBytes) return MVH_OK;
 
   LdsConvArgs a;
+  a.mask_bits = 0; a.bits_out = nullptr;
+  if (o.mask_bits) {  // sign bytes take the place of the float mask
+    if (!bwd || CQ % 4 != 0) return MVH_OK;
+    mask = reinterpret_cast<const float*>(o.mask_bits);
+    a.mask_bits = 1;
+  }
+  if (o.bits_out) {
+    if (bwd || CO % 4 != 0) return MVH_OK;
+    a.bits_out = o.bits_out;
+  }
   a.in = in; a.mask = mask; a.W = prepacked ? prepacked : wpack; a.bias = bias; a.out = out;
   a.rowinfo = lap->rowinfo; a.ell = lap->ell;
   a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;

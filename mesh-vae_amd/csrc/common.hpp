@@ -54,6 +54,10 @@ struct LdsConvOpts {
   float* pooled = nullptr;
   int pooled_bs = 0;
   bool dry_run = false;               // only report eligibility through *handled
+  // ReLU sign bytes [B][rows][C/4] (bit j of byte c/4 = out[v][c+j] > 0): written by the forward
+  // kernel (bits_out) and read by the backward kernels instead of the fp32 output (mask_bits)
+  const uint8_t* mask_bits = nullptr;
+  uint8_t* bits_out = nullptr;
 };
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
@@ -73,13 +77,15 @@ int launch_pack_all(hipStream_t st, const PackTable& t);
 int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias,
                        float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                        size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool = nullptr,
-                       float* pooled = nullptr /* fused one-hot pooling of the output (falls back to a launch) */);
+                       float* pooled = nullptr /* fused one-hot pooling of the output (falls back to a launch) */,
+                       uint8_t* bits_out = nullptr /* ReLU sign bytes [B][N][Cout/4] of the output (Cout % 4 == 0) */);
 int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
                        const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
                        int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,
                        const float* prepacked_bwd, const mvh_csr_t* dout_pool = nullptr /* dout is the gradient of
                        the POOLED output [B, dout_pool->n_rows, Cout]; un-pooling is fused into the loads */,
-                       bool* fused_ok = nullptr /* set false (nothing launched) when that fusion is not available */);
+                       bool* fused_ok = nullptr /* set false (nothing launched) when that fusion is not available */,
+                       const uint8_t* out_bits = nullptr /* sign bytes from the forward; `out` stays the fallback */);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
@@ -88,6 +94,6 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool* handled, int bstride = 0 /* rows per mesh of x/dout/out_mask (0 = N) */,
                     const int32_t* dout_map = nullptr, int dout_rows = 0 /* dout row v = dout[map[v]] (zero if < 0),
                                                                             compact buffer of dout_rows per mesh */,
-                    bool dry_run = false);
+                    bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */);
 
 }  // namespace mvh

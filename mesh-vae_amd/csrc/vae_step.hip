@@ -24,8 +24,11 @@ struct StepPlan {
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat;
   size_t scratch_main, scratch_side, scratch_bytes;
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
+  std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   size_t total;
 };
+
+constexpr size_t kNoBits = ~(size_t)0;
 
 static size_t take(size_t& cur, size_t floats) {
   const size_t o = cur;
@@ -79,6 +82,11 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   }
   p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
   p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
+  p.encBits.assign(n, kNoBits); p.decBits.assign(n, kNoBits);
+  for (int i = 0; i < n; ++i) {  // one byte per vertex and 4 output channels
+    if (p.f[i + 1] % 4 == 0) p.encBits[i] = take(cur, ((size_t)B * p.Nn[i] * (p.f[i + 1] / 4) + 3) / 4);
+    if (p.f[n - i] % 4 == 0) p.decBits[i] = take(cur, ((size_t)B * p.Nn[n - i - 1] * (p.f[n - i] / 4) + 3) / 4);
+  }
   p.scratch_bytes = align_up(scratch, 256);
   p.scratch_main = cur; cur += p.scratch_bytes;
   p.scratch_side = cur; cur += p.scratch_bytes;
@@ -148,6 +156,7 @@ extern "C" int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc) {
 }
 
 #define F(off) ((float*)((char*)ws + (off)))
+#define BITS(off) ((off) == kNoBits ? (uint8_t*)nullptr : (uint8_t*)((char*)ws + (off)))
 #define TRY(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
 
 extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
@@ -197,7 +206,7 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
-                           &d->down[i], F(p.encP[i])));
+                           &d->down[i], F(p.encP[i]), BITS(p.encBits[i])));
     cur = F(p.encP[i]);
   }
   TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], F(p.h), B, p.flat, p.H, MVH_ACT_RELU, u_enc, pd));
@@ -212,7 +221,8 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     TRY(mvh_pool_fwd(stream, &d->up[lvl], cur, F(p.decU[i]), B, cin));
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
-                           nullptr, B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i])));
+                           nullptr, B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i]),
+                           nullptr, nullptr, BITS(p.decBits[i])));
     cur = F(p.decC[i]);
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
@@ -251,20 +261,20 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists
   auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
-                          int K, int act) -> int {
+                          int K, int act, const uint8_t* bits) -> int {
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
       MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
-    return mvh_cheb_conv_bwd((mvh_stream_t)sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N,
-                             cin, cout, K, act, ss, p.scratch_bytes);
+    return cheb_conv_bwd_impl(sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N, cin, cout, K, act,
+                              ss, p.scratch_bytes, nullptr, nullptr, nullptr, bits);
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
-                          int act, size_t pk) -> int {
+                          int act, size_t pk, const uint8_t* bits) -> int {
     return cheb_conv_bwd_impl(main, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
-                              act, sm, p.scratch_bytes, F(pk));
+                              act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits);
   };
 
   // ---- loss
@@ -274,17 +284,17 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   {
     const float* xin = F(p.decC[n - 1]);
     TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
-                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE));
+                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr));
     TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
-                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n]));
+                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr));
   }
   // ---- decoder stages, last to first
   for (int i = n - 1; i >= 0; --i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU));
+                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i])));
     TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i]));
+                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i])));
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     TRY(mvh_pool_bwd(stream, &d->up_t[lvl], F(p.g_decU[i]), dst, B, cin));
   }
@@ -316,19 +326,19 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     }
     TRY(cheb_conv_bwd_impl(sstream, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                            nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, ss,
-                           p.scratch_bytes, nullptr, &d->down[i], &ok_dw));
+                           p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i])));
     if (i > 0)
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
-                             sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx));
+                             sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx, BITS(p.encBits[i])));
     if (ok_dw && ok_dx) continue;
     TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
     if (!ok_dw)
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
-                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU));
+                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i])));
     if (!ok_dx)
       TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
-                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i]));
+                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
   }
   // join
   if (sstream != main) {
