@@ -134,7 +134,8 @@ int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t
 int mvh_linear_fwd(mvh_stream_t stream, const float* x, const float* W, const float* bias,
                    float* y, int32_t B, int32_t in_f, int32_t out_f, int32_t act,
                    const float* drop_u, float p);
-/* dx may be NULL.  `y` is the forward output (mask for relu/dropout).  ws: B*out_f floats. */
+/* dx may be NULL; dW (with db) may be NULL instead (dX-only call).  `y` is the forward output
+ * (mask for relu/dropout).  ws is unused (kept for ABI stability; may be NULL). */
 int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* W, const float* y,
                    const float* dy, float* dx, float* dW, float* db,
                    int32_t B, int32_t in_f, int32_t out_f, int32_t act, float p,

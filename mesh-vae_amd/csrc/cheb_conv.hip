@@ -138,8 +138,44 @@ k_cheb_gstack(const float* __restrict__ dout, const float* __restrict__ out, con
   }
 }
 
+// K == 1 with a narrow dout (the split path of the final 16 -> 3 layer): g0[r][ci] = sum_co dpre[r][co] W[ci][co].
+// One lane per (row, 4 input channels): the lanes of a row write 16 consecutive bytes each, so a wave
+// stores whole rows back to back (the row-per-lane kernel above scatters 16-byte pieces 64 B apart).
+template <int COUT_T>
+__global__ void __launch_bounds__(256)
+k_gstack_rows(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ W,
+              float* __restrict__ g0, long long total, int Cin, int act) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int QV = Cin >> 2, q = (int)(idx % QV);
+  const long long r = idx / QV;
+  float w[4][COUT_T];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int co = 0; co < COUT_T; ++co) w[t][co] = W[(long long)(4 * q + t) * COUT_T + co];
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int co = 0; co < COUT_T; ++co) {
+    float d = dout[r * COUT_T + co];
+    if (act == MVH_ACT_RELU && !(out[r * COUT_T + co] > 0.f)) d = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = fmaf(d, w[t][co], g[t]);
+  }
+  *reinterpret_cast<float4*>(g0 + r * Cin + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
+}
+
 static int launch_gstack(hipStream_t st, const float* dout, const float* out, const float* W, float* G,
                          float* g0, long long rows, int Cin, int Cout, int K, int act) {
+  if (K == 1 && (Cin & 3) == 0 && ((uintptr_t)g0 & 15) == 0 && (Cout == 3 || Cout == 4)) {
+    const long long total = rows * (Cin >> 2);
+    if (Cout == 3)
+      hipLaunchKernelGGL((k_gstack_rows<3>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
+    else
+      hipLaunchKernelGGL((k_gstack_rows<4>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
+    MVH_LAUNCH_CHECK();
+    return MVH_OK;
+  }
   const int grid = cdiv(rows, 256);
 #define MVH_G(CT, FULL)                                                                          \
   hipLaunchKernelGGL((k_cheb_gstack<CT, FULL>), dim3(grid), dim3(256), 0, st, dout, out, W, G, g0, \

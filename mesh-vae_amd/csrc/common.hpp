@@ -96,4 +96,13 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                                                                             compact buffer of dout_rows per mesh */,
                     bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */);
 
+// halves of mvh_vae_latent_bwd: dh + the head pre-activation gradients dpre [B, C + 2Z]; then the weight gradients
+int latent_bwd_heads(hipStream_t st, const float* drop_u, float p, const float* Wc, const float* Wm, const float* Wv,
+                     const float* eps, const float* y_hat, const float* logvar, const float* d_yhat,
+                     const float* d_mu, const float* d_logvar, const float* d_zy, float* dh, float* dpre, int B,
+                     int H, int C, int Z);
+int latent_bwd_wgrad(hipStream_t st, const float* h, const float* y, const float* drop_u, float p, const float* dpre,
+                     float* dWc, float* dbc, float* dWm, float* dbm, float* dWv, float* dbv, int B, int H, int C,
+                     int Z);
+
 }  // namespace mvh

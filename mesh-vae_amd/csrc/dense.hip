@@ -326,7 +326,7 @@ extern "C" int mvh_linear_fwd(mvh_stream_t stream, const float* x, const float* 
 extern "C" int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* W, const float* y,
                               const float* dy, float* dx, float* dW, float* db, int32_t B, int32_t in_f,
                               int32_t out_f, int32_t act, float p, void* ws, size_t ws_bytes) {
-  MVH_REQUIRE(x && W && dy && dW, "linear_bwd: null tensor");
+  MVH_REQUIRE(x && W && dy && (dW || dx), "linear_bwd: null tensor");
   const bool masked = (act == MVH_ACT_RELU);
   MVH_REQUIRE(masked || p == 0.f, "linear_bwd: dropout without relu is not supported");
   MVH_REQUIRE(!masked || y, "linear_bwd: relu/dropout backward needs the forward output");
@@ -339,6 +339,7 @@ extern "C" int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* 
   if (dx)  // dx[b,i] = sum_o dpre[b,o] W[o,i]
     if (int rc = launch_gemm_ex(st, dy, out_f, 1, W, in_f, 1, dx, B, in_f, out_f, nullptr, 0, nullptr, 0.f, mask, scale,
                                 nullptr)) return rc;
+  if (!dW) return MVH_OK;  // dX-only call (the step engine runs the weight gradients on a side stream)
   // dW[o,i] = sum_b dpre[b,o] x[b,i]  and  db[o] = sum_b dpre[b,o] (virtual ones column)
   return launch_gemm_ex(st, dy, 1, out_f, x, in_f, 1, dW, out_f, in_f, B, nullptr, 0, nullptr, 0.f, mask, scale, db);
 }
@@ -371,13 +372,29 @@ extern "C" int mvh_vae_latent_bwd(mvh_stream_t stream, const float* h, const flo
                   dWc && dbc && dWm && dbm && dWv && dbv, "latent_bwd: null tensor");
   const int no = C + 2 * Z;
   MVH_REQUIRE(ws && ws_bytes >= (size_t)B * no * sizeof(float), "latent_bwd: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  float* dpre = (float*)ws;
+  if (int rc = latent_bwd_heads((hipStream_t)stream, drop_u, p, Wc, Wm, Wv, eps, y_hat, logvar, d_yhat, d_mu, d_logvar,
+                                d_zy, dh, (float*)ws, B, H, C, Z)) return rc;
+  return latent_bwd_wgrad((hipStream_t)stream, h, y, drop_u, p, (const float*)ws, dWc, dbc, dWm, dbm, dWv, dbv, B, H, C, Z);
+}
+
+// the two halves of mvh_vae_latent_bwd (the step engine runs the second one on a side stream)
+int mvh::latent_bwd_heads(hipStream_t st, const float* drop_u, float p, const float* Wc, const float* Wm,
+                          const float* Wv, const float* eps, const float* y_hat, const float* logvar,
+                          const float* d_yhat, const float* d_mu, const float* d_logvar, const float* d_zy,
+                          float* dh, float* dpre, int B, int H, int C, int Z) {
+  const int no = C + 2 * Z;
   if (B > 0) {
     hipLaunchKernelGGL(k_latent_bwd, dim3(B), dim3(256), (size_t)no * sizeof(float), st, drop_u, p, Wc, Wm, Wv,
                        eps, y_hat, logvar, d_yhat, d_mu, d_logvar, d_zy, dh, dpre, H, C, Z);
     MVH_LAUNCH_CHECK();
   }
+  return MVH_OK;
+}
+
+int mvh::latent_bwd_wgrad(hipStream_t st, const float* h, const float* y, const float* drop_u, float p,
+                          const float* dpre, float* dWc, float* dbc, float* dWm, float* dbm, float* dWv,
+                          float* dbv, int B, int H, int C, int Z) {
+  const int no = C + 2 * Z;
   hipLaunchKernelGGL(k_latent_wgrad, dim3(cdiv(C + H + 1, 256), no), dim3(256), 0, st, h, y, drop_u, p, dpre,
                      dWc, dbc, dWm, dbm, dWv, dbv, B, H, C, Z);
   MVH_LAUNCH_CHECK();

@@ -21,7 +21,7 @@ struct StepPlan {
   std::vector<int> f;             // filters [n+2]
   // activations (floats): conv outputs / pooled, decoder unpooled / conv outputs
   std::vector<size_t> encA, encP, decU, decC, g_encA, g_encP, g_decU, g_decC;
-  size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat;
+  size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat, d_heads;
   size_t scratch_main, scratch_side, scratch_bytes;
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
@@ -73,6 +73,7 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.d2 = take(cur, (size_t)B * p.flat); p.g_d2 = take(cur, (size_t)B * p.flat);
   p.g_recon = take(cur, (size_t)B * p.Nn[0] * p.F0);
   p.d_mu = take(cur, (size_t)B * p.Z); p.d_lv = take(cur, (size_t)B * p.Z); p.d_yhat = take(cur, (size_t)B * p.C);
+  p.d_heads = take(cur, (size_t)B * (p.C + 2 * p.Z));
   p.pk_enc_f.resize(n); p.pk_enc_b.resize(n); p.pk_dec_f.resize(n + 1); p.pk_dec_b.resize(n + 1);
   for (int i = 0; i < n; ++i) {
     p.pk_enc_f[i] = take(cur, pack_entry_floats(p.f[i], p.f[i + 1], d->K[i], false));
@@ -114,6 +115,7 @@ struct ParamIdx {
 
 struct SideStream {
   hipStream_t stream = nullptr;
+  hipStream_t dense = nullptr;  // second lane: weight gradients of the dense layers + latent heads
   hipEvent_t ev[64];
   int n_ev = 0;
   int next_ev = 0;
@@ -125,13 +127,16 @@ __global__ void __launch_bounds__(256) k_zero(float* __restrict__ p, long long n
   if (i < n) p[i] = 0.f;
 }
 
+// Per host thread: the step engine may be driven by several enqueue threads (one per chain of
+// meshes, engine.py TrainStep n_micro > 1); each gets its own side stream and event ring.
 static SideStream* side_for_device() {
-  static SideStream side[16];
+  static thread_local SideStream side[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream& s = side[dev];
   if (!s.stream) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&s.dense, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     s.n_ev = 64;
@@ -253,6 +258,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     static const char* no_side = getenv("MESHVAE_NO_SIDE");
     if (no_side && no_side[0] == '1') sstream = main;  // debugging aid: weight gradients on the main chain
   }
+  // dense-layer weight gradients: their own lane (they would delay the conv dW chain on `sstream`)
+  hipStream_t dstream = (sstream == main) ? main : (side_stream ? sstream : side->dense);
   void* sm = (char*)ws + p.scratch_main;
   void* ss = (char*)ws + p.scratch_side;
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
@@ -298,21 +305,37 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     TRY(mvh_pool_bwd(stream, &d->up_t[lvl], F(p.g_decU[i]), dst, B, cin));
   }
-  // ---- dense decoder head, latent heads, dense encoder head
-  TRY(mvh_linear_bwd(stream, F(p.d1), P[ix.dl2W()], F(p.d2), F(p.g_d2), F(p.g_d1), G[ix.dl2W()], G[ix.dl2B()], B, p.H,
-                     p.flat, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
-  TRY(mvh_linear_bwd(stream, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), F(p.g_zy), G[ix.decLW()], G[ix.decLB()], B,
-                     p.C + p.Z, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
-  TRY(mvh_vae_latent_bwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar,
-                         F(p.d_yhat), F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), G[ix.clsW()], G[ix.clsB()],
-                         G[ix.zmW()], G[ix.zmB()], G[ix.zvW()], G[ix.zvB()], B, p.H, p.C, p.Z, sm, p.scratch_bytes));
-  TRY(mvh_linear_bwd(stream, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), F(p.g_encP[n - 1]), G[ix.encLW()],
-                     G[ix.encLB()], B, p.flat, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
-  // dec_lin_1 is never used by the forward (cheb_VAE.py:165): zero gradient
-  hipLaunchKernelGGL(k_zero, dim3(cdiv((long long)p.H * (p.C + p.Z), 256)), dim3(256), 0, main, G[ix.dl1W()],
-                     (long long)p.H * (p.C + p.Z));
-  hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, main, G[ix.dl1B()], (long long)p.H);
-  MVH_LAUNCH_CHECK();
+  // ---- dense decoder head, latent heads, dense encoder head: the dX chain stays on the main stream,
+  //      every weight gradient (4 GEMMs + the head gradients) goes to the dense lane after ONE fork
+  TRY(mvh_linear_bwd(stream, F(p.d1), P[ix.dl2W()], F(p.d2), F(p.g_d2), F(p.g_d1), nullptr, nullptr, B, p.H, p.flat,
+                     MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  TRY(mvh_linear_bwd(stream, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), F(p.g_zy), nullptr, nullptr, B, p.C + p.Z,
+                     p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  TRY(latent_bwd_heads(main, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar, F(p.d_yhat),
+                       F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), F(p.d_heads), B, p.H, p.C, p.Z));
+  if (dstream != main) {
+    MVH_HIP(hipEventRecord(side->ev[ev], main));
+    MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
+    ev = (ev + 1) % side->n_ev;
+  }
+  TRY(mvh_linear_bwd(stream, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), F(p.g_encP[n - 1]), nullptr, nullptr,
+                     B, p.flat, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+  {
+    mvh_stream_t ds = (mvh_stream_t)dstream;
+    TRY(mvh_linear_bwd(ds, F(p.d1), P[ix.dl2W()], F(p.d2), F(p.g_d2), nullptr, G[ix.dl2W()], G[ix.dl2B()], B, p.H,
+                       p.flat, MVH_ACT_RELU, pd, nullptr, 0));
+    TRY(mvh_linear_bwd(ds, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), nullptr, G[ix.decLW()], G[ix.decLB()], B,
+                       p.C + p.Z, p.H, MVH_ACT_RELU, pd, nullptr, 0));
+    TRY(latent_bwd_wgrad(dstream, F(p.h), y, u_cls, pd, F(p.d_heads), G[ix.clsW()], G[ix.clsB()], G[ix.zmW()],
+                         G[ix.zmB()], G[ix.zvW()], G[ix.zvB()], B, p.H, p.C, p.Z));
+    TRY(mvh_linear_bwd(ds, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), nullptr, G[ix.encLW()], G[ix.encLB()], B,
+                       p.flat, p.H, MVH_ACT_RELU, pd, nullptr, 0));
+    // dec_lin_1 is never used by the forward (cheb_VAE.py:165): zero gradient
+    hipLaunchKernelGGL(k_zero, dim3(cdiv((long long)p.H * (p.C + p.Z), 256)), dim3(256), 0, dstream, G[ix.dl1W()],
+                       (long long)p.H * (p.C + p.Z));
+    hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, dstream, G[ix.dl1B()], (long long)p.H);
+    MVH_LAUNCH_CHECK();
+  }
   // ---- encoder stages, last to first.  g_encP[i] is the gradient of the POOLED conv output; the
   // one-hot un-pooling is folded into the loads of the dW / dX kernels (no scatter launch, no
   // zero-filled [B, N_i, C] gradient tensor); if a layer is not eligible it is un-pooled explicitly.
@@ -341,6 +364,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                        p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
   }
   // join
+  if (dstream != main && dstream != sstream) {
+    MVH_HIP(hipEventRecord(side->ev[ev], dstream));
+    MVH_HIP(hipStreamWaitEvent(main, side->ev[ev], 0));
+    ev = (ev + 1) % side->n_ev;
+  }
   if (sstream != main) {
     MVH_HIP(hipEventRecord(side->ev[ev], sstream));
     MVH_HIP(hipStreamWaitEvent(main, side->ev[ev], 0));

@@ -105,7 +105,7 @@ class TrainStep:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.use_graph = use_graph
         self.graph_fb = self.graph_opt = None
-        self.out = None
+        self._out = None
         net._eps_provider = lambda B, Z, device: self.eps      # static buffer (graph-safe)
         net._prepare()                                         # topology upload must precede any capture
         # native=True: the whole forward+backward is one C++ launch sequence (mvh_vae_forward/backward);
@@ -114,7 +114,7 @@ class TrainStep:
         # are independent, so the latency-bound small-level kernels of one chain overlap the
         # CU-filling level-0 kernels of another; gradients of the chains are summed before Adam.
         self.n_micro = n_micro if (native and batch % max(n_micro, 1) == 0) else 1
-        self.native, self.streams, self.extra_grads = None, [], []
+        self.native, self.streams, self.extra_grads, self.pool = None, [], [], None
         if native:
             mb = batch // self.n_micro
             self.native = []
@@ -127,45 +127,73 @@ class TrainStep:
                     for p in self.flat.params:
                         grads.append(buf[off:off + p.numel()].view_as(p))
                         off += p.numel()
-                # chain 0 runs on the caller's stream and forks its weight-gradient kernels to a side
-                # stream; chains >= 1 are themselves forks and keep dW inline (a fork of a fork
-                # crashes hipGraph instantiation on ROCm 7.2, tools/capture_probe.py)
+                # chain 0 runs on the caller's stream, chains >= 1 on their own.  Eager: every chain is
+                # enqueued by its own host thread (launching ~90 kernels costs the host ~0.4 ms, so one
+                # thread cannot keep several chains fed) and forks its weight-gradient kernels to that
+                # thread's internal side stream.  MEASURED (tools/host_time.py, tools/thread_probe.py):
+                # the ROCm 7.2 runtime tops out at ~340 k launches/s over all host threads (225 k/s on
+                # one), so two chains cost ~0.75 ms of launching and n_micro = 2 is slower (0.97 ms)
+                # than one chain (0.90 ms); n_micro stays 1 by default.  hipGraph capture: single thread, chain 0 forks to a
+                # torch side stream, chains >= 1 keep dW inline (a fork of a fork crashes graph
+                # instantiation on ROCm 7.2, tools/capture_probe.py).
                 chain = torch.cuda.Stream(self.dev) if j > 0 else None
-                self.streams.append((chain, torch.cuda.Stream(self.dev) if j == 0 else chain))
-                self.native.append(NativeStep(net, mb, grads=grads, side_stream=self.streams[j][1]))
+                if use_graph:
+                    side = chain if j > 0 else torch.cuda.Stream(self.dev)
+                else:
+                    side = None
+                self.streams.append((chain, side))
+                self.native.append(NativeStep(net, mb, grads=grads, side_stream=side))
+            if self.n_micro > 1 and not use_graph:
+                from concurrent.futures import ThreadPoolExecutor
+                self.pool = ThreadPoolExecutor(max_workers=self.n_micro - 1, thread_name_prefix="meshvae-chain")
 
     def load(self, x, x_gt, y):
         self.x.copy_(x, non_blocking=True)
         self.x_gt.copy_(x_gt, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
 
+    def _run_chain(self, j, u, cur):
+        nat, st = self.native[j], self.streams[j][0]
+        mb = self.B // self.n_micro
+        sl = slice(j * mb, (j + 1) * mb)
+        eps = self.eps[sl] if self.m_type == "train" else None
+        with torch.cuda.device(self.dev), torch.cuda.stream(st if st is not None else cur):
+            return nat.forward_backward(self.x[sl], self.x_gt[sl], self.y[sl], eps, u)
+
     def _fwd_bwd(self):
         if self.native is not None:
             train = self.net.training and self.net.dropout.p > 0.0
             cur = torch.cuda.current_stream(self.dev)
             mb = self.B // self.n_micro
-            outs = []
-            for j, nat in enumerate(self.native):
-                st = self.streams[j][0]
-                sl = slice(j * mb, (j + 1) * mb)
+            # dropout uniforms of every chain are drawn first, in chain order, on the caller's stream
+            us = [torch.rand(mb * nat.u_cols, device=self.dev) if train else None for nat in self.native]
+            for st, _ in self.streams:      # fork every chain BEFORE chain 0 queues its work on `cur`
                 if st is not None:
                     st.wait_stream(cur)
-                with torch.cuda.stream(st if st is not None else cur):
-                    u = torch.rand(mb * nat.u_cols, device=self.dev) if train else None
-                    eps = self.eps[sl] if self.m_type == "train" else None
-                    outs.append(nat.forward_backward(self.x[sl], self.x_gt[sl], self.y[sl], eps, u))
+            if self.pool is not None:
+                futs = [self.pool.submit(self._run_chain, j, us[j], cur) for j in range(1, self.n_micro)]
+                outs = [self._run_chain(0, us[0], cur)] + [f.result() for f in futs]
+            else:
+                outs = [self._run_chain(j, us[j], cur) for j in range(self.n_micro)]
             for j in range(1, self.n_micro):
                 cur.wait_stream(self.streams[j][0])
                 self.flat.grad.add_(self.extra_grads[j - 1])
-            if self.n_micro > 1:   # every chain averaged over its own micro-batch
-                self.flat.grad.mul_(1.0 / self.n_micro)
             self._micro_outs = outs
-            self.out = (outs[0][0], outs[0][1], outs[0][2]) if self.n_micro == 1 else None
+            self._out = (outs[0][0], outs[0][1], outs[0][2]) if self.n_micro == 1 else None
             return
         self.flat.zero_grad()
         loss, correct, recon, extra, y_hat = self.net(_Batch(self.x), self.x_gt, self.y, m_type=self.m_type)
         loss.backward()
-        self.out = (loss.detach(), correct, recon.detach())
+        self._out = (loss.detach(), correct, recon.detach())
+
+    @property
+    def out(self):
+        """(loss, correct, recon) of the last step; micro-batched chains are assembled on first access."""
+        if self._out is None and getattr(self, "_micro_outs", None):
+            o = self._micro_outs
+            self._out = (torch.stack([t[0] for t in o]).mean(), torch.stack([t[1] for t in o]).sum(),
+                         torch.cat([t[2] for t in o], 0))
+        return self._out
 
     def capture(self, warmup=3):
         side = torch.cuda.Stream(self.dev)
@@ -181,7 +209,7 @@ class TrainStep:
             self._fwd_bwd()
         self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_opt):
-            self.opt.step(1.0 / self.world)
+            self.opt.step(1.0 / (self.world * self.n_micro))
         torch.cuda.synchronize(self.dev)
 
     def _draw_eps(self):
@@ -202,6 +230,7 @@ class TrainStep:
 
     def step(self):
         self._draw_eps()
+        scale = 1.0 / (self.world * self.n_micro)   # every chain averaged over its own micro-batch
         if self.use_graph:
             if self.graph_fb is None:
                 self.capture()
@@ -211,11 +240,7 @@ class TrainStep:
         else:
             self._fwd_bwd()
             self.flat.all_reduce(self.group)
-            self.opt.step(1.0 / self.world)
-        if self.out is None:     # micro-batched: assemble the (loss, correct, recon) triple lazily
-            o = self._micro_outs
-            self.out = (torch.stack([t[0] for t in o]).mean(), torch.stack([t[1] for t in o]).sum(),
-                        torch.cat([t[2] for t in o], 0))
+            self.opt.step(scale)
         return self.out
 
 
