@@ -200,8 +200,10 @@ int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* e
  * drop_u [B*(3H + flat)] uniforms for the four dropout sites in order (encoder h, classifier,
  * dec_lin, dec_lin_2), NULL = eval.  Activations and their gradients live in `ws`
  * (mvh_vae_step_ws_bytes), which must be passed unchanged from forward to backward.
- * backward overwrites every gradient (dec_lin_1: zeros); its weight-gradient kernels run on an
- * internal side stream forked from and joined to `stream` with events (hipGraph-capturable). */
+ * backward overwrites every gradient (dec_lin_1: zeros); its weight-gradient kernels run on
+ * internal side streams forked from and joined to `stream` with events (hipGraph-capturable).
+ * d_loss: device scalar (dtype of the loss) scaling every gradient, or NULL = 1: the forward
+ * already leaves the d_loss = 1 gradient seeds of the loss in `ws`, so NULL costs no launch. */
 #define MVH_VAE_MAX_LAYERS 8
 typedef struct mvh_vae_desc {
   int32_t n_layers, num_features, num_hidden, num_classes, num_style;

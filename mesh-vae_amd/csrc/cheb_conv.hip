@@ -399,7 +399,7 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
 int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                             const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
                             int act, void* ws, size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool,
-                            float* pooled, uint8_t* bits_out) {
+                            float* pooled, uint8_t* bits_out, const float* weff_pre) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   MVH_REQUIRE(!bits_out || Cout % 4 == 0, "cheb_conv_fwd: sign bytes need Cout %% 4 == 0");
   auto finish = [&](bool bits_done) -> int {  // pooling / sign bytes the main kernel did not produce itself
@@ -415,9 +415,13 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
   if (!tx_saved && ws && ws_bytes >= kLdsWpackBytes + kSplitScratchBytes && split_eligible(lap, N, Cin, Cout, K)) {
-    float* weff = (float*)((char*)ws + kLdsWpackBytes);
-    hipLaunchKernelGGL(k_weff, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, W, weff, K, Cin * Cout);
-    MVH_LAUNCH_CHECK();
+    const float* weff = weff_pre;
+    if (!weff) {
+      float* wbuf = (float*)((char*)ws + kLdsWpackBytes);
+      hipLaunchKernelGGL(k_weff, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, W, wbuf, K, Cin * Cout);
+      MVH_LAUNCH_CHECK();
+      weff = wbuf;
+    }
     if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act)) return rc;
     bool handled = false;
     LdsConvOpts so;
@@ -478,7 +482,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
                             const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                             size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok,
-                            const uint8_t* out_bits) {
+                            const uint8_t* out_bits, const float* weff_pre) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -556,9 +560,12 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     }
   }
   if (split_ok && !dx_done) {  // dx = dpre W_eff^T everywhere, then the connected block overwrites its rows
-    float* weff = split;
-    hipLaunchKernelGGL(k_weff, dim3(cdiv(CC, 256)), dim3(256), 0, st, W, weff, K, CC);
-    MVH_LAUNCH_CHECK();
+    const float* weff = weff_pre;
+    if (!weff) {
+      hipLaunchKernelGGL(k_weff, dim3(cdiv(CC, 256)), dim3(256), 0, st, W, split, K, CC);
+      MVH_LAUNCH_CHECK();
+      weff = split;
+    }
     if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act)) return rc;
     bool handled = false;
     LdsConvOpts so;

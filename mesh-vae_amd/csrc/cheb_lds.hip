@@ -324,6 +324,13 @@ __global__ void __launch_bounds__(256) k_pack_all(PackTable t) {
   const PackEntry e = t.e[blockIdx.y];
   const int NS = (e.CO + 3) >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e.bwd == 2) {  // W_eff = sum_k T_k(0) W_k (isolated vertices of the split path): T_k(0) = 1, 0, -1, 0, ...
+    if (i >= e.Cin * e.Cout) return;
+    float s = 0.f;
+    for (int k = 0; k < e.K; k += 2) s += ((k & 2) ? -1.f : 1.f) * e.W[(long long)k * e.Cin * e.Cout + i];
+    e.dst[i] = s;
+    return;
+  }
   if (i >= NS * e.K * e.CQ * 4) return;
   const int j = i & 3, c = (i >> 2) % e.CQ, k = (i >> 2) / e.CQ % e.K, sl = (i >> 2) / e.CQ / e.K;
   const int o = sl * 4 + j;
@@ -342,7 +349,7 @@ int launch_pack_all(hipStream_t st, const PackTable& t) {
   if (t.n == 0) return MVH_OK;
   int mx = 0;
   for (int i = 0; i < t.n; ++i) {
-    const int nf = ((t.e[i].CO + 3) / 4) * t.e[i].K * t.e[i].CQ * 4;
+    const int nf = t.e[i].bwd == 2 ? t.e[i].Cin * t.e[i].Cout : ((t.e[i].CO + 3) / 4) * t.e[i].K * t.e[i].CQ * 4;
     if (nf > mx) mx = nf;
   }
   hipLaunchKernelGGL(k_pack_all, dim3(cdiv(mx, 256), t.n), dim3(256), 0, st, t);

@@ -65,10 +65,10 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
 struct PackEntry {
   const float* W;
   float* dst;
-  int K, Cin, Cout, CQ, CO, bwd;
+  int K, Cin, Cout, CQ, CO, bwd;  // bwd: 0 forward slabs, 1 W^T slabs, 2 = W_eff [Cin*Cout] of the split path
 };
 struct PackTable {
-  PackEntry e[2 * (MVH_VAE_MAX_LAYERS * 2 + 1)];
+  PackEntry e[2 * (MVH_VAE_MAX_LAYERS * 2 + 1) + 1];
   int n;
 };
 int pack_entry_floats(int Cin, int Cout, int K, bool bwd);
@@ -78,14 +78,16 @@ int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, con
                        float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                        size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool = nullptr,
                        float* pooled = nullptr /* fused one-hot pooling of the output (falls back to a launch) */,
-                       uint8_t* bits_out = nullptr /* ReLU sign bytes [B][N][Cout/4] of the output (Cout % 4 == 0) */);
+                       uint8_t* bits_out = nullptr /* ReLU sign bytes [B][N][Cout/4] of the output (Cout % 4 == 0) */,
+                       const float* weff_pre = nullptr /* W_eff already built by launch_pack_all (split path) */);
 int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
                        const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
                        int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,
                        const float* prepacked_bwd, const mvh_csr_t* dout_pool = nullptr /* dout is the gradient of
                        the POOLED output [B, dout_pool->n_rows, Cout]; un-pooling is fused into the loads */,
                        bool* fused_ok = nullptr /* set false (nothing launched) when that fusion is not available */,
-                       const uint8_t* out_bits = nullptr /* sign bytes from the forward; `out` stays the fallback */);
+                       const uint8_t* out_bits = nullptr /* sign bytes from the forward; `out` stays the fallback */,
+                       const float* weff_pre = nullptr);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
@@ -96,6 +98,11 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                                                                             compact buffer of dout_rows per mesh */,
                     bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */);
 
+// mvh_vae_loss_fwd with optional gradient seeds for d_loss = 1 (d_recon [B*NV], d_mu/d_logvar [B*Z], d_yhat [B*C])
+int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
+                  const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss, void* rec,
+                  float* kld, int64_t* correct, int B, int NV, int C, int Z, void* ws, size_t ws_bytes,
+                  float* d_recon, float* d_mu, float* d_logvar, float* d_yhat);
 // halves of mvh_vae_latent_bwd: dh + the head pre-activation gradients dpre [B, C + 2Z]; then the weight gradients
 int latent_bwd_heads(hipStream_t st, const float* drop_u, float p, const float* Wc, const float* Wm, const float* Wv,
                      const float* eps, const float* y_hat, const float* logvar, const float* d_yhat,

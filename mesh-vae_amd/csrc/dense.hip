@@ -33,38 +33,103 @@ __device__ __forceinline__ void load_k4(const float* __restrict__ base, long lon
     if (k + t < K) v[t] = p[(long long)(k + t) * s_k];
 }
 
+constexpr int kGemmWaves = 8;
+
 template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kGemmWaves)
 k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm, long long sbk,
          long long sbn, float* __restrict__ C, int M, int N, int K, const float* __restrict__ bias, int act,
          const float* __restrict__ drop_u, float p, const float* __restrict__ a_mask, float a_scale,
          float* __restrict__ ones_out) {
-  // one block = one 16x16 output tile; its 4 waves split K (interleaved 16-chunks) and are
-  // summed through LDS in fixed order, so the dependent-load chain per wave is K/64 long.
+  // one block = one 16x16 output tile; its 8 waves split K (interleaved 16-chunks) and are
+  // summed through LDS in fixed order.  These GEMMs are latency-bound (a few MFLOP): the full
+  // 16-chunks run in a branch-free loop unrolled 4x so four chunks of loads are in flight per
+  // wave; rows/columns past the edge are clamped (their results are never stored) and only
+  // the K tail takes the bounds-checked loads.
   // a_mask (same indexing as A): A elements become (mask > 0 ? a * a_scale : 0) on load -- the
   // relu/dropout backward mask of nn.Linear, so no separate "dpre" pass exists.
   // ones_out: a virtual column n == N with B = 1 whose results (row sums of A^T...) go to
   // ones_out[m]: the bias gradient comes out of the dW GEMM for free.
-  __shared__ float red[3][64][4];
+  __shared__ float red[kGemmWaves - 1][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const int i = lane & 15, kq = lane >> 4;
   const bool ones_col = ones_out && (n0 + i == N);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int k0 = wave * 16; k0 < K; k0 += 64) {
-    float a[4], b[4];
-    load_k4<A_KC>(A, sam, sak, m0 + i, M, k0 + 4 * kq, K, a);
-    if (a_mask) {
+  const int arow = min(m0 + i, M - 1), brow = min(n0 + i, N - 1);
+  const float* __restrict__ ap = A + (long long)arow * sam;
+  const float* __restrict__ mp = a_mask ? a_mask + (long long)arow * sam : nullptr;
+  const float* __restrict__ bp = Bm + (long long)brow * sbn;
+  auto load_chunk = [&](int k, float (&a)[4], float (&b)[4]) {  // k .. k+3 all < K
+    if constexpr (A_KC) {
+      const float4 t = *reinterpret_cast<const float4*>(ap + k);
+      a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = ap[(long long)(k + t) * sak];
+    }
+    if (mp) {
       float mk[4];
-      load_k4<A_KC>(a_mask, sam, sak, m0 + i, M, k0 + 4 * kq, K, mk);
+      if constexpr (A_KC) {
+        const float4 t = *reinterpret_cast<const float4*>(mp + k);
+        mk[0] = t.x; mk[1] = t.y; mk[2] = t.z; mk[3] = t.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mk[t] = mp[(long long)(k + t) * sak];
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = mk[t] > 0.f ? a[t] * a_scale : 0.f;
     }
-    load_k4<B_KC>(Bm, sbn, sbk, n0 + i, N, k0 + 4 * kq, K, b);
+    if constexpr (B_KC) {
+      const float4 t = *reinterpret_cast<const float4*>(bp + k);
+      b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = bp[(long long)(k + t) * sbk];
+    }
+    if (ones_col) b[0] = b[1] = b[2] = b[3] = 1.f;
+  };
+  auto mma = [&](const float (&a)[4], const float (&b)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+  };
+  const int Kfull = K & ~15;
+  const int NW = blockDim.x >> 6;  // 1..kGemmWaves waves, chosen from K by the launcher
+  const int kStep = 16 * NW;
+  int k0 = wave * 16;
+  for (; k0 + 3 * kStep < Kfull; k0 += 4 * kStep) {  // four chunks of loads in flight
+    float a[4][4], b[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_chunk(k0 + u * kStep + 4 * kq, a[u], b[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mma(a[u], b[u]);
+  }
+  if (k0 + kStep < Kfull) {  // two
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) load_chunk(k0 + u * kStep + 4 * kq, a[u], b[u]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mma(a[u], b[u]);
+    k0 += 2 * kStep;
+  }
+  for (; k0 < Kfull; k0 += kStep) {
+    float a[4], b[4];
+    load_chunk(k0 + 4 * kq, a, b);
+    mma(a, b);
+  }
+  if (Kfull < K && wave == ((Kfull >> 4) % NW)) {  // K tail: bounds-checked loads
+    float a[4], b[4];
+    load_k4<A_KC>(A, sam, sak, m0 + i, M, Kfull + 4 * kq, K, a);
+    if (a_mask) {
+      float mk[4];
+      load_k4<A_KC>(a_mask, sam, sak, m0 + i, M, Kfull + 4 * kq, K, mk);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = mk[t] > 0.f ? a[t] * a_scale : 0.f;
+    }
+    load_k4<B_KC>(Bm, sbn, sbk, n0 + i, N, Kfull + 4 * kq, K, b);
     if (ones_col) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) b[t] = (k0 + 4 * kq + t < K) ? 1.f : 0.f;
+      for (int t = 0; t < 4; ++t) b[t] = (Kfull + 4 * kq + t < K) ? 1.f : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
@@ -76,7 +141,7 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
   __syncthreads();
   if (wave > 0) return;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
+  for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
   const float keep_scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
@@ -110,8 +175,10 @@ static int launch_gemm_ex(hipStream_t st, const float* A, long long sam, long lo
   const bool akc = (sak == 1) && (sam % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)a_mask % 16 == 0);
   const bool bkc = (sbk == 1) && (sbn % 4 == 0) && ((uintptr_t)Bm % 16 == 0);
   const dim3 grid(cdiv(N + (ones_out ? 1 : 0), 16), cdiv(M, 16));
+  int waves = cdiv(K, 16);  // one 16-chunk of K per wave at least
+  waves = waves < 1 ? 1 : (waves > kGemmWaves ? kGemmWaves : waves);
 #define MVH_GEMM(AK, BK)                                                                                   \
-  hipLaunchKernelGGL((k_gemm16<AK, BK>), grid, dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
+  hipLaunchKernelGGL((k_gemm16<AK, BK>), grid, dim3(64 * waves), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
                      act, drop_u, p, a_mask, a_scale, ones_out)
   if (akc && bkc) MVH_GEMM(true, true);
   else if (akc) MVH_GEMM(true, false);

@@ -12,7 +12,7 @@ constexpr int kLossSplit = 16;  // blocks per mesh for the reconstruction sum
 template <typename GT>
 __global__ void __launch_bounds__(256)
 k_loss_partial(const float* __restrict__ recon, const GT* __restrict__ gt, double inv_sigma,
-               double* __restrict__ partial, int NV) {
+               double* __restrict__ partial, int NV, float* __restrict__ d_recon, double inv_var_over_B) {
   const int b = blockIdx.y, s = blockIdx.x;
   const long long base = (long long)b * NV;
   double acc = 0.0;
@@ -25,6 +25,9 @@ k_loss_partial(const float* __restrict__ recon, const GT* __restrict__ gt, doubl
       d = (double)df;
     }
     acc += 0.5 * d * d;
+    // gradient seed for d_loss = 1 (what k_loss_bwd_recon would write): the step engine skips the
+    // separate backward pass over recon / x_gt
+    if (d_recon) d_recon[base + i] = (float)(inv_var_over_B * ((double)recon[base + i] - (double)gt[base + i]));
   }
   __shared__ double red[256];
   red[threadIdx.x] = acc;
@@ -42,7 +45,8 @@ k_loss_finish(const double* __restrict__ partial, const float* __restrict__ mu,
               const float* __restrict__ logvar, const float* __restrict__ y,
               const float* __restrict__ y_hat, double elem_const, GT* __restrict__ loss,
               GT* __restrict__ rec, float* __restrict__ kld, long long* __restrict__ correct, int B,
-              int NV, int C, int Z, int S) {
+              int NV, int C, int Z, int S, float* __restrict__ d_mu, float* __restrict__ d_logvar,
+              float* __restrict__ d_yhat) {
   __shared__ double red[256];
   __shared__ int redc[256];
   double tot = 0.0;
@@ -55,6 +59,10 @@ k_loss_finish(const double* __restrict__ partial, const float* __restrict__ mu,
     for (int t = 0; t < Z; ++t) {
       const float m = mu[(long long)b * Z + t], lv = logvar[(long long)b * Z + t];
       k += 1.f + lv - m * m - expf(lv);
+      if (d_mu) {  // seeds for d_loss = 1, as k_loss_bwd_small
+        d_mu[(long long)b * Z + t] = (float)(1.0 / (double)B) * m;
+        d_logvar[(long long)b * Z + t] = (float)(1.0 / (double)B) * (-0.5f) * (1.f - expf(lv));
+      }
     }
     k *= -0.5f;
     float q = 0.f;
@@ -65,6 +73,9 @@ k_loss_finish(const double* __restrict__ partial, const float* __restrict__ mu,
       if (yh > y_hat[(long long)b * C + am_hat]) am_hat = c;
       if (yy > y[(long long)b * C + am_y]) am_y = c;
     }
+    if (d_yhat)
+      for (int c = 0; c < C; ++c)
+        d_yhat[(long long)b * C + c] = (float)(1.0 / (double)B) * (-2.f) * y[(long long)b * C + c] / q;
     const GT rec_t = (GT)r;
     rec[b] = rec_t;
     kld[b] = k;
@@ -125,6 +136,14 @@ extern "C" int mvh_vae_loss_fwd(mvh_stream_t stream, const float* recon, const v
                                 const float* mu, const float* logvar, const float* y, const float* y_hat,
                                 float log_sigma, void* loss, void* rec, float* kld, int64_t* correct,
                                 int32_t B, int32_t NV, int32_t C, int32_t Z, void* ws, size_t ws_bytes) {
+  return loss_fwd_impl((hipStream_t)stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld,
+                       correct, B, NV, C, Z, ws, ws_bytes, nullptr, nullptr, nullptr, nullptr);
+}
+
+int mvh::loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
+                       const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss,
+                       void* rec, float* kld, int64_t* correct, int B, int NV, int C, int Z, void* ws,
+                       size_t ws_bytes, float* d_recon, float* d_mu, float* d_logvar, float* d_yhat) {
   MVH_REQUIRE(recon && x_gt && mu && logvar && y && y_hat && loss && rec && kld && correct, "loss_fwd: null tensor");
   MVH_REQUIRE(B > 0 && NV > 0 && C > 0 && Z > 0, "loss_fwd: bad sizes");
   MVH_REQUIRE(ws && ws_bytes >= (size_t)B * kLossSplit * sizeof(double), "loss_fwd: workspace too small");
@@ -133,18 +152,22 @@ extern "C" int mvh_vae_loss_fwd(mvh_stream_t stream, const float* recon, const v
   // exp(log_sigma) in the precision the reference uses (fp32 tensor; cheb_VAE.py:329-330)
   const double sigma = (double)expf(log_sigma);
   const double elem_const = (double)(float)log_sigma + 0.5 * 1.8378770664093453 /* ln(2 pi) */;
+  const double ivb = 1.0 / (sigma * sigma) / (double)B;
+  MVH_REQUIRE(!d_mu || (d_logvar && d_yhat), "loss_fwd: incomplete gradient-seed outputs");
   if (gt_f64) {
     hipLaunchKernelGGL((k_loss_partial<double>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const double*)x_gt,
-                       1.0 / sigma, partial, NV);
+                       1.0 / sigma, partial, NV, d_recon, ivb);
     MVH_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_loss_finish<double>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
-                       elem_const, (double*)loss, (double*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit);
+                       elem_const, (double*)loss, (double*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit,
+                       d_mu, d_logvar, d_yhat);
   } else {
     hipLaunchKernelGGL((k_loss_partial<float>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const float*)x_gt,
-                       1.0 / sigma, partial, NV);
+                       1.0 / sigma, partial, NV, d_recon, ivb);
     MVH_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_loss_finish<float>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
-                       elem_const, (float*)loss, (float*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit);
+                       elem_const, (float*)loss, (float*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit,
+                       d_mu, d_logvar, d_yhat);
   }
   MVH_LAUNCH_CHECK();
   return MVH_OK;

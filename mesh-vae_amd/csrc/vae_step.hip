@@ -24,6 +24,7 @@ struct StepPlan {
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat, d_heads;
   size_t scratch_main, scratch_side, scratch_bytes;
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
+  size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   size_t total;
 };
@@ -83,6 +84,7 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   }
   p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
   p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
+  p.weff_final = take(cur, (size_t)p.f[1] * p.f[0]);
   p.encBits.assign(n, kNoBits); p.decBits.assign(n, kNoBits);
   for (int i = 0; i < n; ++i) {  // one byte per vertex and 4 output channels
     if (p.f[i + 1] % 4 == 0) p.encBits[i] = take(cur, ((size_t)B * p.Nn[i] * (p.f[i + 1] / 4) + 3) / 4);
@@ -203,6 +205,8 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
     }
     add(P[ix.decW(n)], p.pk_dec_f[n], p.f[1], p.f[0], d->K[n], false);
     add(P[ix.decW(n)], p.pk_dec_b[n], p.f[1], p.f[0], d->K[n], true);
+    add(P[ix.decW(n)], p.weff_final, p.f[1], p.f[0], d->K[n], false);
+    t.e[t.n - 1].bwd = 2;
     TRY(launch_pack_all((hipStream_t)stream, t));
   }
   // ---- encoder (cheb_VAE.py:261-273)
@@ -232,10 +236,13 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
   TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
-                         p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n])));
+                         p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n]), nullptr, nullptr, nullptr,
+                         F(p.weff_final)));
   // ---- loss (cheb_VAE.py:321-346)
-  return mvh_vae_loss_fwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld, correct, B,
-                          p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes);
+  // (the gradient seeds of a d_loss = 1 backward come out of the same two launches)
+  return loss_fwd_impl((hipStream_t)stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld,
+                       correct, B, p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes, F(p.g_recon), F(p.d_mu), F(p.d_lv),
+                       F(p.d_yhat));
 }
 
 extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P,
@@ -279,21 +286,22 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
-                          int act, size_t pk, const uint8_t* bits) -> int {
+                          int act, size_t pk, const uint8_t* bits, const float* weff = nullptr) -> int {
     return cheb_conv_bwd_impl(main, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
-                              act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits);
+                              act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits, weff);
   };
 
-  // ---- loss
-  TRY(mvh_vae_loss_bwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, d_loss, F(p.g_recon), F(p.d_mu),
-                       F(p.d_lv), F(p.d_yhat), B, p.Nn[0] * p.F0, p.C, p.Z));
+  // ---- loss: mvh_vae_forward already left the d_loss = 1 seeds in the workspace
+  if (d_loss)
+    TRY(mvh_vae_loss_bwd(stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, d_loss, F(p.g_recon), F(p.d_mu),
+                         F(p.d_lv), F(p.d_yhat), B, p.Nn[0] * p.F0, p.C, p.Z));
   // ---- final conv
   {
     const float* xin = F(p.decC[n - 1]);
     TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
                      p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr));
     TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
-                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr));
+                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr, F(p.weff_final)));
   }
   // ---- decoder stages, last to first
   for (int i = n - 1; i >= 0; --i) {
