@@ -354,6 +354,109 @@ k_dw_combine(float* __restrict__ dW, const float* __restrict__ dWsub, const floa
 
 constexpr size_t kSplitScratchBytes = 64 * 1024;
 
+// K = 1 weight gradient with a narrow dpre (the S_all pass of the split path, final 16 -> 3 layer):
+//   S[ci][co] = sum_rows x[r][ci] dpre[r][co],  db[co] = sum_rows dpre[r][co].
+// A streaming reduction (HBM-bound): QV = CX/4 lanes share a row, each holding 16 B of x and the
+// CD dpre values; lanes with the same channel quad are summed with shuffles, waves through LDS,
+// blocks through `partial` [grid][(CX + 1) * CD] and a one-block finish (fixed order).
+constexpr int kXtyGrid = 1024;
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+k_xty_small(const float* __restrict__ x, const float* __restrict__ d, float* __restrict__ partial, long long rows,
+            int CX) {
+  const int QV = CX >> 2, RPW = 64 / QV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane % QV, rsub = lane / QV;
+  float acc[4][CD], dsum[CD];
+#pragma unroll
+  for (int c = 0; c < CD; ++c) {
+    dsum[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t][c] = 0.f;
+  }
+  const long long stride = (long long)gridDim.x * 4 * RPW;
+#pragma unroll 4
+  for (long long r = ((long long)blockIdx.x * 4 + wave) * RPW + rsub; r < rows; r += stride) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * CX + 4 * q);
+    float dv[CD];
+#pragma unroll
+    for (int c = 0; c < CD; ++c) dv[c] = d[r * CD + c];
+#pragma unroll
+    for (int c = 0; c < CD; ++c) {
+      acc[0][c] = fmaf(xv.x, dv[c], acc[0][c]);
+      acc[1][c] = fmaf(xv.y, dv[c], acc[1][c]);
+      acc[2][c] = fmaf(xv.z, dv[c], acc[2][c]);
+      acc[3][c] = fmaf(xv.w, dv[c], acc[3][c]);
+      dsum[c] += dv[c];
+    }
+  }
+  // lanes q, q + QV, q + 2 QV, ... hold the same channel quad
+  for (int off = QV; off < 64; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CD; ++c) {
+      dsum[c] += __shfl_xor(dsum[c], off, 64);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][c] += __shfl_xor(acc[t][c], off, 64);
+    }
+  }
+  __shared__ float red[4][(32 + 1) * 4];  // [wave][(CX + 1) * CD], CX <= 32, CD <= 4
+  if (lane < QV) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CD; ++c) red[wave][(4 * q + t) * CD + c] = acc[t][c];
+    if (q == 0)
+#pragma unroll
+      for (int c = 0; c < CD; ++c) red[wave][CX * CD + c] = dsum[c];
+  }
+  __syncthreads();
+  const int nout = (CX + 1) * CD;
+  if ((int)threadIdx.x < nout)
+    partial[(long long)blockIdx.x * nout + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(1024)
+k_xty_finish(const float* __restrict__ partial, int nblocks, int nout, int n_s, float* __restrict__ S,
+             float* __restrict__ db) {
+  // thread (g, e): group g of 1024/nout_pad sums blocks g, g + G, ...; groups are then summed in order
+  __shared__ float red[1024];
+  const int G = 1024 / nout;  // >= 7 for nout <= 132
+  const int g = threadIdx.x / nout, e = threadIdx.x - g * nout;
+  float s = 0.f;
+  if (g < G)
+    for (int b = g; b < nblocks; b += G) s += partial[(long long)b * nout + e];
+  red[threadIdx.x] = (g < G) ? s : 0.f;
+  __syncthreads();
+  if ((int)threadIdx.x < nout) {
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += red[k * nout + threadIdx.x];
+    if ((int)threadIdx.x < n_s) S[threadIdx.x] = t;
+    else if (db) db[threadIdx.x - n_s] = t;
+  }
+}
+
+// *handled == false: not eligible (caller keeps the LDS-kernel K = 1 pass)
+static int try_xty_small(hipStream_t st, const float* x, const float* dpre, float* S, float* db, long long rows,
+                         int Cin, int Cout, float* partial, size_t part_bytes, bool* handled) {
+  *handled = false;
+  if ((Cout != 3 && Cout != 4) || (Cin != 8 && Cin != 16 && Cin != 32)) return MVH_OK;
+  if (((uintptr_t)x % 16) != 0 || rows <= 0) return MVH_OK;
+  const int nout = (Cin + 1) * Cout;
+  const int rpb = 4 * (64 / (Cin >> 2));
+  int grid = (int)((rows + rpb - 1) / rpb);
+  if (grid > kXtyGrid) grid = kXtyGrid;
+  if (!partial || part_bytes < (size_t)grid * nout * sizeof(float)) return MVH_OK;
+  if (Cout == 3) hipLaunchKernelGGL((k_xty_small<3>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin);
+  else hipLaunchKernelGGL((k_xty_small<4>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin);
+  MVH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_xty_finish, dim3(1), dim3(1024), 0, st, partial, grid, nout, Cin * Cout, S, db);
+  MVH_LAUNCH_CHECK();
+  *handled = true;
+  return MVH_OK;
+}
+
 // fallback producer of the ReLU sign bytes (the LDS kernel writes them in its epilogue)
 __global__ void __launch_bounds__(256)
 k_relu_bits(const float* __restrict__ out, uint8_t* __restrict__ bits, long long n) {
@@ -549,7 +652,10 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     const float* mask = act == MVH_ACT_RELU ? out : nullptr;
     bool h1 = false, h2 = false;
-    if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1)) return rc;
+    if (!mask)  // S_all is a plain x^T dpre reduction: stream it instead of running the LDS kernel with K = 1
+      if (int rc = try_xty_small(st, x, dout, S, db, rows, Cin, Cout, partial, pbytes, &h1)) return rc;
+    if (!h1)
+      if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1)) return rc;
     if (h1)
       if (int rc = try_cheb_dw_lds(st, lap->sub, x, dout, mask, dWsub, nullptr, B, lap->n_active, Cin, Cout, K, partial,
                                    pbytes, &h2, N)) return rc;
