@@ -350,14 +350,17 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   for (int i = n - 1; i >= 0; --i) {
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
     bool ok_dw = false, ok_dx = (i == 0);
-    if (sstream != main) {
+    // layer 0 has no dX: the main stream has nothing left to do, so its dW runs there (no fork
+    // latency, and it does not queue behind the side lane's backlog of layers 2 and 1)
+    hipStream_t dws = (i == 0) ? main : sstream;
+    if (dws != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
-      MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+      MVH_HIP(hipStreamWaitEvent(dws, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
-    TRY(cheb_conv_bwd_impl(sstream, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
-                           nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, ss,
-                           p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i])));
+    TRY(cheb_conv_bwd_impl(dws, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
+                           nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
+                           dws == main ? sm : ss, p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i])));
     if (i > 0)
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
