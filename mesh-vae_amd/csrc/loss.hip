@@ -51,19 +51,31 @@ k_loss_finish(const double* __restrict__ partial, const float* __restrict__ mu,
   __shared__ int redc[256];
   double tot = 0.0;
   int corr = 0;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  // four lanes per mesh: the S partial sums and the Z latent terms are split four ways and
+  // combined with two xor-shuffles (a one-thread-per-mesh loop left 3/4 of the block idle and
+  // made this single-block kernel a 10 us stop on the critical path)
+  const int sub = threadIdx.x & 3;
+  for (int b0 = 0; b0 < B; b0 += blockDim.x >> 2) {
+    const int b = b0 + (threadIdx.x >> 2);
+    const bool live = b < B;
+    const int bb = live ? b : 0;
     double r = 0.0;
-    for (int s = 0; s < S; ++s) r += partial[(long long)b * S + s];
-    r += (double)NV * elem_const;
+    for (int s = sub; s < S; s += 4) r += partial[(long long)bb * S + s];
     float k = 0.f;
-    for (int t = 0; t < Z; ++t) {
-      const float m = mu[(long long)b * Z + t], lv = logvar[(long long)b * Z + t];
+    for (int t = sub; t < Z; t += 4) {
+      const float m = mu[(long long)bb * Z + t], lv = logvar[(long long)bb * Z + t];
       k += 1.f + lv - m * m - expf(lv);
-      if (d_mu) {  // seeds for d_loss = 1, as k_loss_bwd_small
+      if (d_mu && live) {  // seeds for d_loss = 1, as k_loss_bwd_small
         d_mu[(long long)b * Z + t] = (float)(1.0 / (double)B) * m;
         d_logvar[(long long)b * Z + t] = (float)(1.0 / (double)B) * (-0.5f) * (1.f - expf(lv));
       }
     }
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    k += __shfl_xor(k, 1, 64);
+    k += __shfl_xor(k, 2, 64);
+    if (!live || sub != 0) continue;
+    r += (double)NV * elem_const;
     k *= -0.5f;
     float q = 0.f;
     int am_hat = 0, am_y = 0;

@@ -24,25 +24,34 @@ def shard_range(global_batch, rank, world):
 
 
 class FlatParams:
-    """Re-homes every parameter (and its .grad) of `module` as a view into one flat buffer."""
+    """Re-homes every parameter (and its .grad) of `module` as a view into one flat buffer.
+    Every tensor starts on a 256-byte boundary (the kernels take 16-byte vector loads of weight
+    rows only from aligned bases); the padding holds zeros in both buffers and stays zero under
+    Adam, so `numel` (padded) is what the all-reduce and the optimizer run over and `n_params`
+    is the model's parameter count."""
+
+    ALIGN = 64  # floats
 
     def __init__(self, module):
         params = [p for p in module.parameters()]
         if not params:
             raise ValueError("module has no parameters")
         dev, dtype = params[0].device, params[0].dtype
-        self.numel = sum(p.numel() for p in params)
-        self.param = torch.empty(self.numel, dtype=dtype, device=dev)
+        self.n_params = sum(p.numel() for p in params)
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.numel = off
+        self.param = torch.zeros(self.numel, dtype=dtype, device=dev)
         self.grad = torch.zeros(self.numel, dtype=dtype, device=dev)
         self.names = [n for n, _ in module.named_parameters()]
-        off = 0
-        for p in params:
+        for p, off in zip(params, offs):
             n = p.numel()
             self.param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.param[off:off + n].view_as(p)
             p.grad = self.grad[off:off + n].view_as(p)
-            off += n
-        self.params = params
+        self.params, self.offsets = params, offs
 
     def zero_grad(self):
         self.grad.zero_()
@@ -123,10 +132,7 @@ class TrainStep:
                 if j > 0:
                     buf = torch.zeros_like(self.flat.grad)
                     self.extra_grads.append(buf)
-                    grads, off = [], 0
-                    for p in self.flat.params:
-                        grads.append(buf[off:off + p.numel()].view_as(p))
-                        off += p.numel()
+                    grads = [buf[off:off + p.numel()].view_as(p) for p, off in zip(self.flat.params, self.flat.offsets)]
                 # chain 0 runs on the caller's stream, chains >= 1 on their own.  Eager: every chain is
                 # enqueued by its own host thread (launching ~90 kernels costs the host ~0.4 ms, so one
                 # thread cannot keep several chains fed) and forks its weight-gradient kernels to that

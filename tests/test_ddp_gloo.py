@@ -35,23 +35,26 @@ def _worker(rank, world, port, out_dir):
     before = {k: v.clone() for k, v in net.state_dict().items()}
     flat = FlatParams(net)
     # re-homing keeps values, names and order; params and grads are views of the flat buffers
-    assert flat.numel == sum(v.numel() for v in before.values())
+    # (every tensor starts on a 256-byte boundary; the padding is zero in both buffers)
+    assert flat.n_params == sum(v.numel() for v in before.values()) and flat.numel >= flat.n_params
     for k, v in net.state_dict().items():
         assert torch.equal(v, before[k])
-    off = 0
-    for p in net.parameters():
+    for p, off in zip(net.parameters(), flat.offsets):
+        assert off % 64 == 0
         assert p.data_ptr() == flat.param.data_ptr() + 4 * off and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * off
-        off += p.numel()
+    assert float(flat.param.abs().sum()) == float(sum(v.abs().sum() for v in before.values()))
     # every rank owns a contiguous shard of the global batch
     G = 10
     lo, hi = shard_range(G, rank, world)
     sample_grads = torch.arange(G, dtype=torch.float32).view(G, 1) * torch.ones(1, flat.numel) + 0.5
     flat.zero_grad()
-    for p in net.parameters():                      # "backward": accumulate into the .grad views
-        p.grad += sample_grads[lo:hi].sum(0)[:p.numel()].view_as(p)
+    for p, off in zip(net.parameters(), flat.offsets):   # "backward": accumulate into the .grad views
+        p.grad += sample_grads[lo:hi].sum(0)[off:off + p.numel()].view_as(p)
     w = flat.all_reduce()
     assert w == world
-    want = sample_grads.sum(0)
+    want = torch.zeros(flat.numel)
+    for p, off in zip(net.parameters(), flat.offsets):
+        want[off:off + p.numel()] = sample_grads.sum(0)[off:off + p.numel()]
     torch.testing.assert_close(flat.grad, want)     # sum over ALL samples == single-rank large batch
     torch.save(flat.grad.clone(), os.path.join(out_dir, f"g{rank}.pt"))
     dist.barrier()
