@@ -585,7 +585,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
                             const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                             size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok,
-                            const uint8_t* out_bits, const float* weff_pre) {
+                            const uint8_t* out_bits, const float* weff_pre, DwReduceEntry* defer,
+                            float* defer_part, size_t defer_bytes, bool* deferred) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -595,6 +596,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
   if (act != MVH_ACT_RELU || Cout % 4 != 0) out_bits = nullptr;
+  if (deferred) *deferred = false;
+  if (!defer || !defer_part || !deferred) defer = nullptr;
   char* p = (char*)ws;
   float* wpack = (float*)p;
   p += kLdsWpackBytes;
@@ -617,7 +620,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     *fused_ok = false;
     if (tx_saved || !dout_pool->sel_inv) return MVH_OK;
     const float* mask = act == MVH_ACT_RELU ? out : nullptr;
-    const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    if (defer) { partial = defer_part; pbytes = defer_bytes; }
     bool ok_dw = (dW == nullptr), ok_dx = (dx == nullptr);
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd; bo.in_map = dout_pool->sel_inv; bo.in_bs = dout_pool->n_rows; bo.mask_bs = N;
@@ -631,9 +635,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
         return rc;
     if (!ok_dw || !ok_dx) return MVH_OK;  // caller un-pools explicitly and calls again without dout_pool
     bool h = false;
-    if (dW)
+    if (dW) {
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &h, 0,
-                                   dout_pool->sel_inv, dout_pool->n_rows, false, out_bits)) return rc;
+                                   dout_pool->sel_inv, dout_pool->n_rows, false, out_bits, defer)) return rc;
+      if (defer && h) *deferred = true;
+    }
     if (dx) {
       bo.dry_run = false;
       if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &h, bo))
@@ -681,9 +687,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     dx_done = handled;
   }
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
-    const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
+    const size_t pbytes = defer ? defer_bytes : (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
-                                 partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits)) return rc;
+                                 defer ? defer_part : partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits, defer))
+      return rc;
+    if (defer && dw_done) *deferred = true;
   }
   if (!dw_done) {
     const float* tx = tx_saved;

@@ -351,14 +351,17 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 // Sum the per-(mesh, wave) partial tiles in fixed order and scatter into dW [K][Cin][Cout] / db.
 // part layout [slab][mesh*NW + wave][tile]; one block = 64 consecutive tile entries x 16 groups
 // of partials, every thread keeps 4 independent running sums (loads pipelined, fixed order).
-__global__ void __launch_bounds__(1024)
-k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NS, int K, int CQ, int CP, int p_is_x,
-            int Cin, int Cout, int db_mode, float* __restrict__ dW, float* __restrict__ db) {
+__device__ __forceinline__ void dw_reduce_body(const DwReduceEntry& t, int block) {
+  const float* __restrict__ part = t.part;
+  const int n_part = t.n_part, NS = t.NS, K = t.K, CQ = t.CQ, CP = t.CP, p_is_x = t.p_is_x, Cin = t.Cin, Cout = t.Cout,
+            db_mode = t.db_mode;
+  float* __restrict__ dW = t.dW;
+  float* __restrict__ db = t.db;
   __shared__ float red[16][64];
   const int tile = (K + 1) * CQ * 4;  // floats per (slab, mesh, wave)
   const int n_out = NS * tile;
   const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + lo;
+  const int o = block * 64 + lo;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (o < n_out) {
     const int sl = o / tile, e = o - sl * tile;
@@ -389,6 +392,30 @@ k_dw_reduce(const float* __restrict__ part, int n_part /* B*NW */, int NS, int K
     if (db_mode == 1 && sl == 0 && j == 0) db[q] = s;  // Q = dpre: db[co = q]
     if (db_mode == 2 && q == 0 && p < CP) db[p] = s;    // P = dpre: db[co = p]
   }
+}
+
+__global__ void __launch_bounds__(1024) k_dw_reduce(DwReduceEntry t) { dw_reduce_body(t, blockIdx.x); }
+
+// Every deferred layer of a step in ONE launch (blockIdx.y = layer): the step engine leaves the
+// partial tiles of each conv layer in its own buffer and reduces them all after the join, which
+// takes ~10 dependent 5 us launches off the weight-gradient lane.
+__global__ void __launch_bounds__(1024) k_dw_reduce_all(DwReduceTable t) {
+  const DwReduceEntry& e = t.e[blockIdx.y];
+  const int n_out = e.NS * (e.K + 1) * e.CQ * 4;
+  if ((int)blockIdx.x * 64 >= n_out) return;  // uniform per block
+  dw_reduce_body(e, blockIdx.x);
+}
+
+int launch_dw_reduce_all(hipStream_t st, const DwReduceTable& t) {
+  if (t.n == 0) return MVH_OK;
+  int mx = 0;
+  for (int i = 0; i < t.n; ++i) {
+    const int n_out = t.e[i].NS * (t.e[i].K + 1) * t.e[i].CQ * 4;
+    if (n_out > mx) mx = n_out;
+  }
+  hipLaunchKernelGGL(k_dw_reduce_all, dim3(cdiv(mx, 64), t.n), dim3(1024), 0, st, t);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
 }
 
 template <int CQ, int VPT, int TCT, int PW>
@@ -436,7 +463,7 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
-                    const uint8_t* out_bits) {
+                    const uint8_t* out_bits, DwReduceEntry* defer) {
   *handled = false;
   const char* e = getenv("MESHVAE_FORCE_GENERIC");
   if (e && e[0] == '1') return MVH_OK;
@@ -485,9 +512,13 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
   if (rc) return rc;
   const int n_out = NS * (K + 1) * CQ * 4;
-  hipLaunchKernelGGL(k_dw_reduce, dim3(cdiv(n_out, 64)), dim3(1024), 0, st, part, B * NW, NS, K, CQ, CP,
-                     p_is_x ? 1 : 0, Cin, Cout, d.db_mode, dW, db);
-  MVH_LAUNCH_CHECK();
+  DwReduceEntry ent{part, B * NW, NS, K, CQ, CP, p_is_x ? 1 : 0, Cin, Cout, d.db_mode, dW, db};
+  if (defer) {
+    *defer = ent;  // the caller reduces later (launch_dw_reduce_all); `part` must stay untouched until then
+  } else {
+    hipLaunchKernelGGL(k_dw_reduce, dim3(cdiv(n_out, 64)), dim3(1024), 0, st, ent);
+    MVH_LAUNCH_CHECK();
+  }
   *handled = true;
   return MVH_OK;
 }

@@ -45,6 +45,18 @@ int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, co
                 long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
                 int act, const float* drop_u, float p);
 
+// deferred reduction of the dW partial tiles (one launch for all conv layers of a step)
+struct DwReduceEntry {
+  const float* part;
+  int n_part, NS, K, CQ, CP, p_is_x, Cin, Cout, db_mode;
+  float* dW;
+  float* db;
+};
+struct DwReduceTable {
+  DwReduceEntry e[2 * MVH_VAE_MAX_LAYERS + 1];
+  int n;
+};
+int launch_dw_reduce_all(hipStream_t st, const DwReduceTable& t);
 // LDS-resident fused ChebConv (cheb_lds.hip); *handled == false -> caller uses the general pipeline
 struct LdsConvOpts {
   const float* prepacked = nullptr;   // slab-packed weights already built (launch_pack_all)
@@ -87,7 +99,10 @@ int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* la
                        the POOLED output [B, dout_pool->n_rows, Cout]; un-pooling is fused into the loads */,
                        bool* fused_ok = nullptr /* set false (nothing launched) when that fusion is not available */,
                        const uint8_t* out_bits = nullptr /* sign bytes from the forward; `out` stays the fallback */,
-                       const float* weff_pre = nullptr);
+                       const float* weff_pre = nullptr,
+                       DwReduceEntry* defer = nullptr /* with defer_part: the LDS dW kernel writes its partial tiles */,
+                       float* defer_part = nullptr    /* there and *defer describes the pending reduction         */,
+                       size_t defer_bytes = 0, bool* deferred = nullptr);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
@@ -96,7 +111,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool* handled, int bstride = 0 /* rows per mesh of x/dout/out_mask (0 = N) */,
                     const int32_t* dout_map = nullptr, int dout_rows = 0 /* dout row v = dout[map[v]] (zero if < 0),
                                                                             compact buffer of dout_rows per mesh */,
-                    bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */);
+                    bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */,
+                    DwReduceEntry* defer = nullptr /* skip the reduce launch and describe it here instead */);
 
 // mvh_vae_loss_fwd with optional gradient seeds for d_loss = 1 (d_recon [B*NV], d_mu/d_logvar [B*Z], d_yhat [B*C])
 int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,

@@ -24,6 +24,8 @@ struct StepPlan {
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat, d_heads;
   size_t scratch_main, scratch_side, scratch_bytes;
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
+  std::vector<size_t> dwPartEnc, dwPartDec;  // per-layer dW partial tiles (reduced together after the join)
+  std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
   size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   size_t total;
@@ -85,6 +87,13 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
   p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
   p.weff_final = take(cur, (size_t)p.f[1] * p.f[0]);
+  p.dwPartEnc.resize(n); p.dwPartDec.resize(n); p.dwPartBytesEnc.resize(n); p.dwPartBytesDec.resize(n);
+  for (int i = 0; i < n; ++i) {
+    p.dwPartBytesEnc[i] = cheb_dw_lds_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]);
+    p.dwPartEnc[i] = take(cur, p.dwPartBytesEnc[i] / sizeof(float) + 1);
+    p.dwPartBytesDec[i] = cheb_dw_lds_ws_bytes(B, p.Nn[n - i - 1], p.f[n + 1 - i], p.f[n - i], d->K[i]);
+    p.dwPartDec[i] = take(cur, p.dwPartBytesDec[i] / sizeof(float) + 1);
+  }
   p.encBits.assign(n, kNoBits); p.decBits.assign(n, kNoBits);
   for (int i = 0; i < n; ++i) {  // one byte per vertex and 4 output channels
     if (p.f[i + 1] % 4 == 0) p.encBits[i] = take(cur, ((size_t)B * p.Nn[i] * (p.f[i + 1] / 4) + 3) / 4);
@@ -272,17 +281,24 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
   const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
+  DwReduceTable red;        // pending dW reductions: one launch after the join
+  red.n = 0;
   // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists
   auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
-                          int K, int act, const uint8_t* bits) -> int {
+                          int K, int act, const uint8_t* bits, size_t part_off = kNoBits, size_t part_bytes = 0) -> int {
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
       MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
-    return cheb_conv_bwd_impl(sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N, cin, cout, K, act,
-                              ss, p.scratch_bytes, nullptr, nullptr, nullptr, bits);
+    bool deferred = false;
+    const bool can = part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
+    TRY(cheb_conv_bwd_impl(sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N, cin, cout, K, act,
+                           ss, p.scratch_bytes, nullptr, nullptr, nullptr, bits, nullptr, can ? &red.e[red.n] : nullptr,
+                           can ? F(part_off) : nullptr, part_bytes, &deferred));
+    if (deferred) ++red.n;
+    return MVH_OK;
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
@@ -307,7 +323,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   for (int i = n - 1; i >= 0; --i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i])));
+                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]),
+                     p.dwPartDec[i], p.dwPartBytesDec[i]));
     TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i])));
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
@@ -358,9 +375,12 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       MVH_HIP(hipStreamWaitEvent(dws, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
+    bool deferred = false;
     TRY(cheb_conv_bwd_impl(dws, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                            nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
-                           dws == main ? sm : ss, p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i])));
+                           dws == main ? sm : ss, p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i]),
+                           nullptr, &red.e[red.n], F(p.dwPartEnc[i]), p.dwPartBytesEnc[i], &deferred));
+    if (deferred) ++red.n;
     if (i > 0)
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
@@ -369,7 +389,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
     if (!ok_dw)
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
-                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i])));
+                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
+                       p.dwPartEnc[i], p.dwPartBytesEnc[i]));
     if (!ok_dx)
       TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
                        p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
@@ -385,6 +406,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     MVH_HIP(hipStreamWaitEvent(main, side->ev[ev], 0));
     ev = (ev + 1) % side->n_ev;
   }
+  TRY(launch_dw_reduce_all(main, red));  // every deferred dW / db in one launch
   return MVH_OK;
 }
 
