@@ -586,7 +586,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                             size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok,
                             const uint8_t* out_bits, const float* weff_pre, DwReduceEntry* defer,
-                            float* defer_part, size_t defer_bytes, bool* deferred) {
+                            float* defer_part, size_t defer_bytes, bool* deferred, const mvh_csr_t* dx_pool_t,
+                            float* dx_pooled) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
@@ -701,25 +702,43 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     }
     if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
   }
-  if (dx_done) return MVH_OK;
+  auto pool_dx = [&]() -> int {  // fallback for dx_pool_t: dx was materialised, pool it with one more launch
+    if (dx_pool_t && dx_pooled && dx)
+      return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+    return MVH_OK;
+  };
+  if (dx_done) return pool_dx();
   {  // fused dX: the same LDS-resident Clenshaw kernel with W^T and the masked dout as input
     bool handled = false;
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd;
     bo.mask_bits = out_bits;
+    if (dx_pool_t && dx_pooled) {  // pooled rows straight from the kernel (dx itself is not materialised)
+      bo.out_pool_t = dx_pool_t;
+      if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx_pooled, B, N, Cin,
+                                Cout, K, act, true, wpack, &handled, bo)) return rc;
+      if (handled) return MVH_OK;
+      bo.out_pool_t = nullptr;
+    }
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
                               Cout, K, act, true, wpack, &handled, bo)) return rc;
-    if (handled) return MVH_OK;
+    if (handled) {
+      if (dx_pool_t && dx_pooled) return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+      return MVH_OK;
+    }
   }
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
   float* g0 = (K == 1) ? dx : G;
   if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act)) return rc;
-  if (K == 1) return MVH_OK;
+  if (K == 1) return pool_dx();
   for (int k = K - 2; k >= 1; --k) {
     float* bk = G + (long long)k * plane;
     const float* bk2 = (k + 2 < K) ? G + (long long)(k + 2) * plane : nullptr;
     if (int rc = launch_spmm(st, lap_t, G + (long long)(k + 1) * plane, bk, bk, bk2, 2.f, -1.f, B, Cin, false))
       return rc;
   }
-  return launch_spmm(st, lap_t, G + plane, dx, G, (K > 2) ? G + 2 * plane : nullptr, 1.f, -1.f, B, Cin, false);
+  if (int rc = launch_spmm(st, lap_t, G + plane, dx, G, (K > 2) ? G + 2 * plane : nullptr, 1.f, -1.f, B, Cin, false))
+    return rc;
+  if (dx_pool_t && dx_pooled) return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+  return MVH_OK;
 }

@@ -41,6 +41,10 @@ struct LdsConvArgs {
   const int32_t* in_map;    // optional: row v of the input is in[in_map[v]] (zero when < 0)
   const int32_t* pool_inv;  // optional fused one-hot pooling: out row v also goes to pooled[pool_inv[v]]
   float* pooled;
+  const int* pt_rowptr;     // optional (backward): the output rows are pooled by this CSR (n_rows = pt_rows) inside
+  const int* pt_col;        // the kernel and ONLY the pooled rows [B][pt_rows][CO] are stored to `out`
+  const float* pt_val;
+  int pt_rows;
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -52,7 +56,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
-  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits;
+  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -66,6 +70,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
            const float* __restrict__ p_bias, float* __restrict__ p_out, const uint32_t* __restrict__ p_rowinfo,
            const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_in_map,
            const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, uint8_t* __restrict__ p_bits_out,
+           const int* __restrict__ p_pt_rowptr, const int* __restrict__ p_pt_col, const float* __restrict__ p_pt_val,
            LdsConvDims a) {
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;  // vertex slots (> N)
@@ -272,9 +277,19 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   }
   float* outb = p_out + (long long)mesh * a.out_bs * a.CO;
   const bool vec_store = slab_full && (a.CO % 4 == 0);
+  // fused transposed pooling of the result (backward of the decoder's upsampling, nn/pool.py U): the
+  // rows go to the slab instead of HBM and every thread then gathers its coarse rows from LDS in
+  // the operator's CSR order (the arithmetic of k_spmm<.., EXACT>): no [B, N, C] gradient tensor
+  const bool scatter = BWD && p_pt_rowptr != nullptr;
+  if (scatter) __syncthreads();  // the last gathers of u_1 are done: the slab is free
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
+    if (scatter && v < N) {
+      const float inv_s = ka2[vi] < 0.f ? __builtin_amdgcn_rsqf(-0.5f * ka2[vi]) : 1.0f;
+      slab[v] = make_float4(R[vi].x * inv_s, R[vi].y * inv_s, R[vi].z * inv_s, R[vi].w * inv_s);
+      continue;
+    }
     if (v >= N) continue;
     // -0.5 * ka2 = 1/deg  ->  rsq(1/deg) = sqrt(deg)
     const float inv_s = ka2[vi] < 0.f ? __builtin_amdgcn_rsqf(-0.5f * ka2[vi]) : 1.0f;
@@ -300,6 +315,22 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           dst[j] = o[j];
           if (pr >= 0) pdst[j] = o[j];
         }
+    }
+  }
+  if (scatter) {
+    __syncthreads();
+    for (int c = tid; c < a.pt_rows; c += THREADS) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int e1 = p_pt_rowptr[c + 1];
+      for (int e = p_pt_rowptr[c]; e < e1; ++e) {
+        const float w = p_pt_val[e];
+        const float4 n = slab[p_pt_col[e]];
+        acc.x = __fadd_rn(acc.x, __fmul_rn(w, n.x));
+        acc.y = __fadd_rn(acc.y, __fmul_rn(w, n.y));
+        acc.z = __fadd_rn(acc.z, __fmul_rn(w, n.z));
+        acc.w = __fadd_rn(acc.w, __fmul_rn(w, n.w));
+      }
+      *reinterpret_cast<float4*>(outb + (long long)c * a.CO + s0) = acc;
     }
   }
 }
@@ -379,9 +410,9 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
-                a.mask_bits};
+                a.mask_bits, a.pt_rows};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
-                     a.in_map, a.pool_inv, a.pooled, a.bits_out, d);
+                     a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -457,6 +488,13 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.mask_bs = o.mask_bs > 0 ? o.mask_bs : a.in_bs;
   a.in_map = o.in_map; a.pool_inv = o.pool_inv; a.pooled = o.pooled; a.pooled_bs = o.pooled_bs;
   if (o.pool_inv && (!o.pooled || ((uintptr_t)o.pooled % 16) != 0)) return MVH_OK;
+  a.pt_rowptr = nullptr; a.pt_col = nullptr; a.pt_val = nullptr; a.pt_rows = 0;
+  if (o.out_pool_t) {  // `out` is the pooled [B][n_rows][CO] buffer
+    const mvh_csr_t* pt = o.out_pool_t;
+    if (!bwd || CO % 4 != 0 || pt->n_cols != N || !pt->rowptr || !pt->col || !pt->val || o.pool_inv) return MVH_OK;
+    a.pt_rowptr = pt->rowptr; a.pt_col = pt->col; a.pt_val = pt->val; a.pt_rows = pt->n_rows;
+    a.out_bs = pt->n_rows;
+  }
   if (o.dry_run) {  // eligibility probe only: nothing is launched
     *handled = true;
     return MVH_OK;

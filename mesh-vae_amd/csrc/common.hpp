@@ -70,6 +70,9 @@ struct LdsConvOpts {
   // kernel (bits_out) and read by the backward kernels instead of the fp32 output (mask_bits)
   const uint8_t* mask_bits = nullptr;
   uint8_t* bits_out = nullptr;
+  // backward only: pool the result rows with this CSR (n_cols = N) inside the kernel; `out` is then the
+  // pooled buffer [B][n_rows][CO] and the un-pooled rows are never stored
+  const mvh_csr_t* out_pool_t = nullptr;
 };
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
@@ -102,7 +105,9 @@ int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* la
                        const float* weff_pre = nullptr,
                        DwReduceEntry* defer = nullptr /* with defer_part: the LDS dW kernel writes its partial tiles */,
                        float* defer_part = nullptr    /* there and *defer describes the pending reduction         */,
-                       size_t defer_bytes = 0, bool* deferred = nullptr);
+                       size_t defer_bytes = 0, bool* deferred = nullptr,
+                       const mvh_csr_t* dx_pool_t = nullptr /* store dx_pooled = dx_pool_t * dx instead of dx (the      */,
+                       float* dx_pooled = nullptr           /* decoder's upsampling backward); falls back to dx + spmm */);
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);

@@ -302,9 +302,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
-                          int act, size_t pk, const uint8_t* bits, const float* weff = nullptr) -> int {
+                          int act, size_t pk, const uint8_t* bits, const float* weff = nullptr,
+                          const mvh_csr_t* pool_t = nullptr, float* pooled = nullptr) -> int {
     return cheb_conv_bwd_impl(main, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
-                              act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits, weff);
+                              act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits, weff, nullptr, nullptr, 0,
+                              nullptr, pool_t, pooled);
   };
 
   // ---- loss: mvh_vae_forward already left the d_loss = 1 seeds in the workspace
@@ -325,10 +327,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]),
                      p.dwPartDec[i], p.dwPartBytesDec[i]));
-    TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i])));
+    // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
-    TRY(mvh_pool_bwd(stream, &d->up_t[lvl], F(p.g_decU[i]), dst, B, cin));
+    TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
+                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]),
+                     nullptr, &d->up_t[lvl], dst));
   }
   // ---- dense decoder head, latent heads, dense encoder head: the dX chain stays on the main stream,
   //      every weight gradient (4 GEMMs + the head gradients) goes to the dense lane after ONE fork
