@@ -544,9 +544,17 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     fo.prepacked = prepacked;
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
     fo.bits_out = bits_out;
+    bool pooled_in_kernel = fo.pool_inv != nullptr;
+    if (pool && pooled && !fo.pool_inv) {  // general operator (the decoder's upsampling): pooled from LDS in the epilogue
+      fo.out_pool_t = pool; fo.pooled = pooled;
+      if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled, fo))
+        return rc;
+      if (handled) return finish(true);
+      fo.out_pool_t = nullptr; fo.pooled = nullptr;
+    }
     if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled, fo))
       return rc;
-    if (handled && pool && !fo.pool_inv)
+    if (handled && pool && !pooled_in_kernel)
       if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
     if (handled) return finish(true);
   }

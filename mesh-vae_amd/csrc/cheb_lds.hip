@@ -277,15 +277,16 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   }
   float* outb = p_out + (long long)mesh * a.out_bs * a.CO;
   const bool vec_store = slab_full && (a.CO % 4 == 0);
-  // fused transposed pooling of the result (backward of the decoder's upsampling, nn/pool.py U): the
-  // rows go to the slab instead of HBM and every thread then gathers its coarse rows from LDS in
-  // the operator's CSR order (the arithmetic of k_spmm<.., EXACT>): no [B, N, C] gradient tensor
-  const bool scatter = BWD && p_pt_rowptr != nullptr;
+  // fused pooling of the result by a general CSR operator (nn/pool.py U forward, U^T backward): the
+  // rows also go to the slab and every thread then gathers its pooled rows from LDS in the
+  // operator's CSR order (the arithmetic of k_spmm<.., EXACT>).  Backward: ONLY the pooled rows are
+  // stored (to `out`; no [B, N, C] gradient tensor); forward: `out` as usual + pooled rows to `pooled`.
+  const bool scatter = p_pt_rowptr != nullptr;
   if (scatter) __syncthreads();  // the last gathers of u_1 are done: the slab is free
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
-    if (scatter && v < N) {
+    if (BWD && scatter && v < N) {
       const float inv_s = ka2[vi] < 0.f ? __builtin_amdgcn_rsqf(-0.5f * ka2[vi]) : 1.0f;
       slab[v] = make_float4(R[vi].x * inv_s, R[vi].y * inv_s, R[vi].z * inv_s, R[vi].w * inv_s);
       continue;
@@ -302,6 +303,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     if (!BWD && p_bits_out)  // CO % 4 == 0 (checked on the host): one sign byte per (vertex, slab)
       p_bits_out[((long long)mesh * a.out_bs + v) * (a.CO >> 2) + (s0 >> 2)] =
           (uint8_t)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
+    if (!BWD && scatter) slab[v] = make_float4(o[0], o[1], o[2], o[3]);
     float* dst = outb + (long long)v * a.CO + s0;
     const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
@@ -330,7 +332,8 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
         acc.z = __fadd_rn(acc.z, __fmul_rn(w, n.z));
         acc.w = __fadd_rn(acc.w, __fmul_rn(w, n.w));
       }
-      *reinterpret_cast<float4*>(outb + (long long)c * a.CO + s0) = acc;
+      float* pb = BWD ? outb : p_pooled + (long long)mesh * a.pooled_bs * a.CO;
+      *reinterpret_cast<float4*>(pb + (long long)c * a.CO + s0) = acc;
     }
   }
 }
@@ -491,9 +494,11 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.pt_rowptr = nullptr; a.pt_col = nullptr; a.pt_val = nullptr; a.pt_rows = 0;
   if (o.out_pool_t) {  // `out` is the pooled [B][n_rows][CO] buffer
     const mvh_csr_t* pt = o.out_pool_t;
-    if (!bwd || CO % 4 != 0 || pt->n_cols != N || !pt->rowptr || !pt->col || !pt->val || o.pool_inv) return MVH_OK;
+    if (CO % 4 != 0 || pt->n_cols != N || !pt->rowptr || !pt->col || !pt->val || o.pool_inv) return MVH_OK;
+    if (!bwd && (!o.pooled || ((uintptr_t)o.pooled % 16) != 0)) return MVH_OK;
     a.pt_rowptr = pt->rowptr; a.pt_col = pt->col; a.pt_val = pt->val; a.pt_rows = pt->n_rows;
-    a.out_bs = pt->n_rows;
+    if (bwd) a.out_bs = pt->n_rows;
+    else { a.pooled = o.pooled; a.pooled_bs = pt->n_rows; }
   }
   if (o.dry_run) {  // eligibility probe only: nothing is launched
     *handled = true;

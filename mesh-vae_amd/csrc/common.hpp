@@ -70,8 +70,8 @@ struct LdsConvOpts {
   // kernel (bits_out) and read by the backward kernels instead of the fp32 output (mask_bits)
   const uint8_t* mask_bits = nullptr;
   uint8_t* bits_out = nullptr;
-  // backward only: pool the result rows with this CSR (n_cols = N) inside the kernel; `out` is then the
-  // pooled buffer [B][n_rows][CO] and the un-pooled rows are never stored
+  // pool the result rows with this CSR (n_cols = N) inside the kernel.  Backward: `out` is then the pooled
+  // buffer [B][n_rows][CO] and the un-pooled rows are never stored; forward: `out` as usual, pooled rows to `pooled`
   const mvh_csr_t* out_pool_t = nullptr;
 };
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,

@@ -234,13 +234,15 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   // ---- decoder (cheb_VAE.py:275-292)
   TRY(mvh_linear_fwd(stream, F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H, MVH_ACT_RELU, u_d1, pd));
   TRY(mvh_linear_fwd(stream, F(p.d1), P[ix.dl2W()], P[ix.dl2B()], F(p.d2), B, p.H, p.flat, MVH_ACT_RELU, u_d2, pd));
-  cur = F(p.d2);
+  // the first upsampling takes the dense head's output; the later ones are produced by the previous
+  // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
+  TRY(mvh_pool_fwd(stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), B, p.f[n + 1]));
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
-    TRY(mvh_pool_fwd(stream, &d->up[lvl], cur, F(p.decU[i]), B, cin));
+    const bool more = i + 1 < n;
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
                            nullptr, B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i]),
-                           nullptr, nullptr, BITS(p.decBits[i])));
+                           more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr, BITS(p.decBits[i])));
     cur = F(p.decC[i]);
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
