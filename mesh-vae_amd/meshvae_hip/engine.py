@@ -109,7 +109,8 @@ class TrainStep:
         n0, f0 = net.num_nodes[0], net.filters[0]
         self.x = torch.zeros(batch, n0, f0, device=self.dev)
         self.x_gt = torch.zeros(batch, n0, f0, device=self.dev)
-        self.y = torch.zeros(batch, net.num_class, dtype=torch.int64, device=self.dev)
+        # one-hot labels as fp32 (what the kernels read): copy_() from the loader's int64 labels converts once
+        self.y = torch.zeros(batch, net.num_class, dtype=torch.float32, device=self.dev)
         self.eps = torch.zeros(batch, net.z, device=self.dev)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.use_graph = use_graph
@@ -322,20 +323,24 @@ class NativeStep:
         import ctypes
         L = lib()
         x, x_gt = x.contiguous(), x_gt.contiguous()
-        self.y_f.copy_(y)
+        if y.dtype == torch.float32 and y.is_contiguous() and y.device == self.dev:
+            y_f = y                      # already what the kernels read: no per-step conversion launch
+        else:
+            self.y_f.copy_(y)
+            y_f = self.y_f
         loss, rec = self._outs(x_gt.dtype)
         f64 = int(x_gt.dtype == torch.float64)
         d = ctypes.byref(self.desc)
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         with torch.cuda.device(self.dev):
             st = torch.cuda.current_stream(self.dev).cuda_stream
-            check(L.mvh_vae_forward(st, d, self._P, x.data_ptr(), self.y_f.data_ptr(), x_gt.data_ptr(), f64, ptr(eps),
+            check(L.mvh_vae_forward(st, d, self._P, x.data_ptr(), y_f.data_ptr(), x_gt.data_ptr(), f64, ptr(eps),
                                     ptr(drop_u), self.B, self.log_sigma, loss.data_ptr(), self.correct.data_ptr(),
                                     self.recon.data_ptr(), self.kld.data_ptr(), rec.data_ptr(), self.z_.data_ptr(),
                                     self.y_hat.data_ptr(), self.mu.data_ptr(), self.logvar.data_ptr(),
                                     self.ws.data_ptr(), self.ws_bytes))
             if backward:
-                check(L.mvh_vae_backward(st, d, self._P, self._G, x.data_ptr(), self.y_f.data_ptr(), x_gt.data_ptr(),
+                check(L.mvh_vae_backward(st, d, self._P, self._G, x.data_ptr(), y_f.data_ptr(), x_gt.data_ptr(),
                                          f64, ptr(eps), ptr(drop_u), self.B, self.log_sigma, None, self.recon.data_ptr(),
                                          self.y_hat.data_ptr(), self.mu.data_ptr(), self.logvar.data_ptr(),
                                          self.ws.data_ptr(), self.ws_bytes,
