@@ -285,21 +285,69 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
   DwReduceTable red;        // pending dW reductions: one launch after the join
   red.n = 0;
-  // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists
-  auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
-                          const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
-                          int K, int act, const uint8_t* bits, size_t part_off = kNoBits, size_t part_bytes = 0) -> int {
+  // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists.
+  // The launches go through a small queue so that several layers can share one fork (event record
+  // on the main stream + wait on the side stream): every queued item's inputs exist when it is
+  // queued, so forking later is always safe.  MEASURED: sharing forks (MESHVAE_FORK_BATCH=2..4) is
+  // 3 % SLOWER than one fork per layer (the default, 1) -- the ~7 us gaps a rocprofv3 timeline
+  // shows at the forks are tracing overhead, while starting a layer's dW later lengthens the tail.
+  struct PendingDw {
+    const mvh_csr_t *lap, *lap_t;
+    const float *xin, *W, *out, *dout;
+    float *dW, *db;
+    int N, cin, cout, K, act;
+    const uint8_t* bits;
+    size_t part_off, part_bytes;
+    const mvh_csr_t *dout_pool, *unpool_t;  // dout is the gradient of the POOLED output (fused un-pooling);
+    float* unpooled;                        // fallback: un-pool with unpool_t into this buffer first
+  };
+  PendingDw pending[4];
+  int n_pending = 0;
+  static const int fork_batch = [] {
+    const char* e = getenv("MESHVAE_FORK_BATCH");
+    const int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : (v > 4 ? 4 : v);
+  }();
+  auto flush_dw = [&](bool also_dense) -> int {  // one event for everything queued (+ the dense lane)
+    if (n_pending == 0 && !also_dense) return MVH_OK;
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
-      MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+      if (n_pending > 0) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+      if (also_dense && (dstream != sstream || n_pending == 0)) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
-    bool deferred = false;
-    const bool can = part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
-    TRY(cheb_conv_bwd_impl(sstream, lap, lap_t, xin, W, out, dout, nullptr, nullptr, dW, db, B, N, cin, cout, K, act,
-                           ss, p.scratch_bytes, nullptr, nullptr, nullptr, bits, nullptr, can ? &red.e[red.n] : nullptr,
-                           can ? F(part_off) : nullptr, part_bytes, &deferred));
-    if (deferred) ++red.n;
+    for (int q = 0; q < n_pending; ++q) {
+      const PendingDw& w = pending[q];
+      bool deferred = false, fused = false;
+      const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
+      const float* dout = w.dout;
+      if (w.dout_pool) {
+        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, nullptr, nullptr, w.dW, w.db, B, w.N,
+                               w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, w.dout_pool, &fused, w.bits,
+                               nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
+                               &deferred));
+        if (!fused) {  // not eligible: explicit un-pooling on this lane, then the plain call below
+          TRY(mvh_pool_bwd((mvh_stream_t)sstream, w.unpool_t, w.dout, w.unpooled, B, w.cout));
+          dout = w.unpooled;
+        }
+      }
+      if (!fused)
+        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, nullptr, nullptr, w.dW, w.db, B, w.N,
+                               w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
+                               can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred));
+      if (deferred) ++red.n;
+    }
+    n_pending = 0;
+    return MVH_OK;
+  };
+  auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
+                          const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
+                          int K, int act, const uint8_t* bits, size_t part_off = kNoBits, size_t part_bytes = 0,
+                          const mvh_csr_t* dout_pool = nullptr, const mvh_csr_t* unpool_t = nullptr,
+                          float* unpooled = nullptr) -> int {
+    pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
+                                     dout_pool, unpool_t, unpooled};
+    if (n_pending >= fork_batch) return flush_dw(false);
     return MVH_OK;
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
@@ -343,11 +391,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                      p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
   TRY(latent_bwd_heads(main, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar, F(p.d_yhat),
                        F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), F(p.d_heads), B, p.H, p.C, p.Z));
-  if (dstream != main) {
-    MVH_HIP(hipEventRecord(side->ev[ev], main));
-    MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
-    ev = (ev + 1) % side->n_ev;
-  }
+  TRY(flush_dw(true));  // one fork: queued conv dW -> side lane, dense weight gradients -> dense lane
   TRY(mvh_linear_bwd(stream, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), F(p.g_encP[n - 1]), nullptr, nullptr,
                      B, p.flat, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
   {
@@ -371,35 +415,43 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // zero-filled [B, N_i, C] gradient tensor); if a layer is not eligible it is un-pooled explicitly.
   for (int i = n - 1; i >= 0; --i) {
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
-    bool ok_dw = false, ok_dx = (i == 0);
-    // layer 0 has no dX: the main stream has nothing left to do, so its dW runs there (no fork
-    // latency, and it does not queue behind the side lane's backlog of layers 2 and 1)
-    hipStream_t dws = (i == 0) ? main : sstream;
-    if (dws != main) {
-      MVH_HIP(hipEventRecord(side->ev[ev], main));
-      MVH_HIP(hipStreamWaitEvent(dws, side->ev[ev], 0));
-      ev = (ev + 1) % side->n_ev;
-    }
-    bool deferred = false;
-    TRY(cheb_conv_bwd_impl(dws, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
-                           nullptr, G[ix.encW(i)], G[ix.encB(i)], B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
-                           dws == main ? sm : ss, p.scratch_bytes, nullptr, &d->down[i], &ok_dw, BITS(p.encBits[i]),
-                           nullptr, &red.e[red.n], F(p.dwPartEnc[i]), p.dwPartBytesEnc[i], &deferred));
-    if (deferred) ++red.n;
-    if (i > 0)
+    if (i > 0) {
+      // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible)
+      TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
+                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
+                       p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i])));
+      bool ok_dx = false;
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
                              sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx, BITS(p.encBits[i])));
-    if (ok_dw && ok_dx) continue;
-    TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), F(p.g_encA[i]), B, p.f[i + 1]));
-    if (!ok_dw)
-      TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), G[ix.encW(i)],
-                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
-                       p.dwPartEnc[i], p.dwPartBytesEnc[i]));
-    if (!ok_dx)
-      TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encA[i]), F(p.g_encP[i - 1]),
-                       p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
+      if (!ok_dx) {  // (its own un-pooled copy: the side lane may be writing g_encA for the dW fallback)
+        // (decoder buffer of the same level, free by now, when it is wide enough)
+        float* tmp = (p.f[i + 2] >= p.f[i + 1]) ? F(p.g_decU[n - 1 - i]) : F(p.g_encA[i]);
+        TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), tmp, B, p.f[i + 1]));
+        TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), tmp, F(p.g_encP[i - 1]), p.Nn[i],
+                         p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
+      }
+      continue;
+    }
+    // layer 0 has no dX: the main stream has nothing left to do, so its dW runs there (no fork
+    // latency, no queueing behind the side lane).  Everything still queued is forked FIRST, or it
+    // would wait behind this kernel.
+    TRY(flush_dw(false));
+    bool ok_dw = false, deferred = false;
+    TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]), nullptr,
+                           nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
+                           p.scratch_bytes, nullptr, &d->down[0], &ok_dw, BITS(p.encBits[0]), nullptr, &red.e[red.n],
+                           F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred));
+    if (!ok_dw) {
+      TRY(mvh_pool_bwd(stream, &d->down_t[0], F(p.g_encP[0]), F(p.g_encA[0]), B, p.f[1]));
+      TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encA[0]), nullptr,
+                             nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
+                             p.scratch_bytes, nullptr, nullptr, nullptr, BITS(p.encBits[0]), nullptr, &red.e[red.n],
+                             F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred));
+    }
+    if (deferred) ++red.n;
   }
+  TRY(flush_dw(false));
   // join
   if (dstream != main && dstream != sstream) {
     MVH_HIP(hipEventRecord(side->ev[ev], dstream));
