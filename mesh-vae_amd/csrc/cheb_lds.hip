@@ -391,13 +391,9 @@ int launch_pack_all(hipStream_t st, const PackTable& t) {
   return MVH_OK;
 }
 
-static bool force_generic() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MESHVAE_FORCE_GENERIC");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
+static bool force_generic() {  // read per call: the tests flip it inside one process
+  const char* e = getenv("MESHVAE_FORCE_GENERIC");
+  return e && e[0] == '1';
 }
 
 template <int CQ, int VPT, int TCT, int PW, bool BWD>

@@ -79,6 +79,54 @@ def test_cheb_conv_cases(ops_npz, topotiny_npz):
             torch.testing.assert_close(conv.bias.grad.cpu(), _t(ops_npz[f"{case}_gb"]), rtol=1e-4, atol=1e-4)
 
 
+def test_cheb_conv_cases_generic_pipeline(ops_npz, topotiny_npz, monkeypatch):
+    """The same golden cases through the general (non-LDS) pipeline: the path every template too large
+    for one CU's LDS takes (BASELINE configs[3], 20k vertices)."""
+    monkeypatch.setenv("MESHVAE_FORCE_GENERIC", "1")
+    test_cheb_conv_cases(ops_npz, topotiny_npz)
+
+
+def _grid_mesh_edges(side):
+    """Triangulated side x side grid: 4-neighbours plus one diagonal per cell, both directions."""
+    idx = np.arange(side * side).reshape(side, side)
+    pairs = [(idx[:, :-1], idx[:, 1:]), (idx[:-1, :], idx[1:, :]), (idx[:-1, :-1], idx[1:, 1:])]
+    src = np.concatenate([a.ravel() for a, _ in pairs] + [b.ravel() for _, b in pairs])
+    dst = np.concatenate([b.ravel() for _, b in pairs] + [a.ravel() for a, _ in pairs])
+    return np.vstack([src, dst]).astype(np.int64)
+
+
+def test_cheb_conv_20k_template_k10_matches_oracle():
+    """BASELINE configs[3] shape: a 20k-vertex template with K=10 (too large for the LDS-resident
+    kernels: 142 x 142 = 20164 vertices) against the CPU oracle, forward and all three gradients."""
+    from nn.conv import ChebConv_batch
+    from oracle import cheb_oracle as O
+    dev = _dev()
+    side, B, cin, cout, K = 142, 2, 16, 16, 10
+    N = side * side
+    ei_cpu = torch.from_numpy(_grid_mesh_edges(side))
+    g = torch.Generator().manual_seed(20)
+    x = torch.randn(B, N, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    gy = torch.randn(B, N, cout, generator=g)
+    eio, nrmo = O.cheb_norm(ei_cpu, N)
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = O.cheb_conv(xo, eio, nrmo, wo, bo)
+    yo.backward(gy)
+    ei, nrm = ChebConv_batch.norm(ei_cpu.to(dev), N)
+    conv = ChebConv_batch(cin, cout, K).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+    xd = x.to(dev).requires_grad_(True)
+    y = conv(xd, ei, nrm)
+    torch.testing.assert_close(y.cpu(), yo.detach(), rtol=0, atol=FWD_ATOL)
+    y.backward(gy.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(conv.weight.grad.cpu(), wo.grad, rtol=1e-4, atol=2e-3)   # sums over 40k rows
+    torch.testing.assert_close(conv.bias.grad.cpu(), bo.grad, rtol=1e-4, atol=2e-3)
+
+
 def test_cheb_conv_fused_relu_and_first_layer(ops_npz, topotiny_npz):
     from nn.conv import ChebConv_batch
     dev = _dev()
