@@ -70,7 +70,8 @@ def kernel_rooflines(net, B, dev):
     st = torch.cuda.current_stream(dev).cuda_stream
     plane = B * N * C * 4                                   # bytes of one [B, N, 16] fp32 tensor
     x = torch.randn(B, N, C, device=dev)
-    out = torch.randn(B, N, Cout, device=dev)
+    out = torch.empty(B, N, Cout, device=dev)
+    signs = torch.empty(B, N, Cout // 4, dtype=torch.uint8, device=dev)
     dout = torch.randn(B, N, Cout, device=dev)
     W = torch.randn(K, C, Cout, device=dev) * 0.1
     bias = torch.zeros(Cout, device=dev)
@@ -78,33 +79,35 @@ def kernel_rooflines(net, B, dev):
     ws_b = L.mvh_cheb_conv_bwd_ws_bytes(B, N, C, Cout, K)
     ws = workspace(ws_b, dev)
     res = {}
+    sign_bytes = B * N * (Cout // 4)
 
+    # the ops exactly as the train step runs them: fused ReLU with its signs kept as bytes
     def fwd():
-        check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                  None, B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
-    res["k_cheb_lds<16,10,512,4,false> (+k_pack_w): conv fwd L0 16->16"] = dict(
-        ms=time_kernel(fwd), bytes=2 * plane, launches_per_step=2)          # read x, write out
+        check(L.mvh_cheb_conv_fwd_signs(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                        signs.data_ptr(), B, N, C, Cout, K, ws.data_ptr(), ws_b))
+    res["k_cheb_lds<16,5,1024,4,false> (+k_pack_w): conv+relu fwd L0 16->16"] = dict(
+        ms=time_kernel(fwd), bytes=2 * plane + sign_bytes, launches_per_step=1)      # read x; write out, signs
 
     def bwd_dw():
-        check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                  dout.data_ptr(), None, None, dW.data_ptr(), db.data_ptr(),
-                                  B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
+        check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                        signs.data_ptr(), dout.data_ptr(), None, dW.data_ptr(), db.data_ptr(),
+                                        B, N, C, Cout, K, ws.data_ptr(), ws_b))
     res["k_cheb_dw_lds<16,10,512,4> (+k_dw_reduce): conv dW/db L0 16->16"] = dict(
-        ms=time_kernel(bwd_dw), bytes=3 * plane, launches_per_step=3)       # read x, dout, relu mask
+        ms=time_kernel(bwd_dw), bytes=2 * plane + sign_bytes, launches_per_step=1)   # read x, dout, relu signs
 
-    def bwd():
-        check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                  dout.data_ptr(), None, dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                                  B, N, C, Cout, K, 1, ws.data_ptr(), ws_b))
-    res["mvh_cheb_conv_bwd L0 16->16 (dW + dX kernels)"] = dict(
-        ms=time_kernel(bwd), bytes=6 * plane, launches_per_step=1)          # dW pass 3 planes + dX pass 3 planes
+    def bwd_dx():
+        check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                        signs.data_ptr(), dout.data_ptr(), dx.data_ptr(), None, None,
+                                        B, N, C, Cout, K, ws.data_ptr(), ws_b))
+    res["k_cheb_lds<16,5,1024,4,true> (+k_pack_w): conv dX L0 16->16"] = dict(
+        ms=time_kernel(bwd_dx), bytes=2 * plane + sign_bytes, launches_per_step=1)   # read dout, signs; write dx
     return res
 
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/): rocprofv3
     cannot be driven from inside this process, so the counters are collected separately and read here."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     try:
         table = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):

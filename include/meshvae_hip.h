@@ -127,6 +127,19 @@ int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t
                       const float* tx_saved, float* dx, float* dW, float* db,
                       int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
                       void* ws, size_t ws_bytes);
+/* The fused conv + ReLU of cheb_VAE.py:264/:285 with the ReLU SIGNS kept as one byte per vertex and
+ * four output channels (relu_signs [B,N,Cout/4]: bit j of byte c/4 = out[b,v,c+j] > 0; Cout % 4 == 0):
+ * the forward writes them from its epilogue, the backward reads them instead of the fp32 output
+ * (1/16 of the bytes).  `out` must still be passed to the backward (fallback paths use it). */
+int mvh_cheb_conv_fwd_signs(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
+                            const float* bias, float* out, uint8_t* relu_signs,
+                            int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K,
+                            void* ws, size_t ws_bytes);
+int mvh_cheb_conv_bwd_signs(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
+                            const float* x, const float* W, const float* out, const uint8_t* relu_signs,
+                            const float* dout, float* dx, float* dW, float* db,
+                            int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K,
+                            void* ws, size_t ws_bytes);
 
 /* ---- rows E/D (dense parts): nn.Linear + F.relu + nn.Dropout (cheb_VAE.py:270-272,277-280).
  * y[B,out] = drop( act( x[B,in] W[out,in]^T + bias ) ); drop keeps element i when

@@ -499,6 +499,14 @@ extern "C" int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                             nullptr, nullptr, nullptr);
 }
 
+extern "C" int mvh_cheb_conv_fwd_signs(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
+                                       const float* bias, float* out, uint8_t* relu_signs, int32_t B, int32_t N,
+                                       int32_t Cin, int32_t Cout, int32_t K, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(relu_signs != nullptr, "cheb_conv_fwd_signs: null relu_signs");
+  return cheb_conv_fwd_impl((hipStream_t)stream, lap, x, W, bias, out, nullptr, B, N, Cin, Cout, K, MVH_ACT_RELU, ws,
+                            ws_bytes, nullptr, nullptr, nullptr, relu_signs);
+}
+
 int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                             const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
                             int act, void* ws, size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool,
@@ -587,6 +595,15 @@ extern "C" int mvh_cheb_conv_bwd(mvh_stream_t stream, const mvh_csr_t* lap, cons
                                  size_t ws_bytes) {
   return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, x, W, out, dout, tx_saved, dx, dW, db, B, N, Cin, Cout, K,
                             act, ws, ws_bytes, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mvh_cheb_conv_bwd_signs(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
+                                       const float* x, const float* W, const float* out, const uint8_t* relu_signs,
+                                       const float* dout, float* dx, float* dW, float* db, int32_t B, int32_t N,
+                                       int32_t Cin, int32_t Cout, int32_t K, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(relu_signs != nullptr && Cout % 4 == 0, "cheb_conv_bwd_signs: relu_signs need Cout %% 4 == 0");
+  return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, x, W, out, dout, nullptr, dx, dW, db, B, N, Cin, Cout, K,
+                            MVH_ACT_RELU, ws, ws_bytes, nullptr, nullptr, nullptr, relu_signs);
 }
 
 int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,

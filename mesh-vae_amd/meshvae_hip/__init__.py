@@ -56,6 +56,8 @@ SIGNATURES = {
     "mvh_cheb_conv_fwd": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _Z]),
     "mvh_cheb_conv_bwd_ws_bytes": (_Z, [_I] * 5),
     "mvh_cheb_conv_bwd": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 6 + [_P, _Z]),
+    "mvh_cheb_conv_fwd_signs": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 5 + [_P, _Z]),
+    "mvh_cheb_conv_bwd_signs": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 5 + [_P, _Z]),
     "mvh_linear_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F]),
     "mvh_linear_bwd": (ctypes.c_int, [_P] * 8 + [_I] * 4 + [_F, _P, _Z]),
     "mvh_vae_latent_fwd": (ctypes.c_int, [_P, _P, _P, _P, _F] + [_P] * 12 + [_I] * 4),

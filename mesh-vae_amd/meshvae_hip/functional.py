@@ -102,15 +102,22 @@ class ChebConvFn(torch.autograd.Function):
                 # no T_k stack is saved: the fused kernels recompute the recurrence on chip
                 ws_bytes = L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K)
                 ws = workspace(ws_bytes, x.device)
-            check(L.mvh_cheb_conv_fwd(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
-                                      out.data_ptr(), _ptr(tx), B, N, Cin, Cout, K, act, _ptr(ws), ws_bytes))
+            signs = None
+            if act and Cout % 4 == 0 and K > 1:
+                # fused ReLU: keep its signs as one byte per 4 channels, the backward reads those
+                signs = torch.empty(B, N, Cout // 4, dtype=torch.uint8, device=x.device)
+                check(L.mvh_cheb_conv_fwd_signs(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                                out.data_ptr(), signs.data_ptr(), B, N, Cin, Cout, K, _ptr(ws), ws_bytes))
+            else:
+                check(L.mvh_cheb_conv_fwd(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                          out.data_ptr(), _ptr(tx), B, N, Cin, Cout, K, act, _ptr(ws), ws_bytes))
         ctx.op, ctx.act, ctx.has_bias = op, act, bias is not None
-        ctx.save_for_backward(x, weight, out if act else None, tx)
+        ctx.save_for_backward(x, weight, out if act else None, tx, signs)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, weight, out, tx = ctx.saved_tensors
+        x, weight, out, tx, signs = ctx.saved_tensors
         op, act = ctx.op, ctx.act
         dout = dout.contiguous()
         B, N, Cin = x.shape
@@ -122,9 +129,14 @@ class ChebConvFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             ws_bytes = L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K)
             ws = workspace(ws_bytes, x.device)
-            check(L.mvh_cheb_conv_bwd(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
-                                      _ptr(out), dout.data_ptr(), _ptr(tx), _ptr(dx), dW.data_ptr(), _ptr(db),
-                                      B, N, Cin, Cout, K, act, ws.data_ptr(), ws_bytes))
+            if signs is not None:
+                check(L.mvh_cheb_conv_bwd_signs(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
+                                                out.data_ptr(), signs.data_ptr(), dout.data_ptr(), _ptr(dx),
+                                                dW.data_ptr(), _ptr(db), B, N, Cin, Cout, K, ws.data_ptr(), ws_bytes))
+            else:
+                check(L.mvh_cheb_conv_bwd(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
+                                          _ptr(out), dout.data_ptr(), _ptr(tx), _ptr(dx), dW.data_ptr(), _ptr(db),
+                                          B, N, Cin, Cout, K, act, ws.data_ptr(), ws_bytes))
         return dx, dW, db, None, None
 
 

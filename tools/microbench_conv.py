@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--dwonly", action="store_true", help="backward without dX (weight/bias gradient kernels only)")
     ap.add_argument("--relu", type=int, default=1)
+    ap.add_argument("--signs", type=int, default=1, help="fused-ReLU ops keep the ReLU signs as bytes (the train step's form)")
     args = ap.parse_args()
 
     from meshvae_hip import check, lib, topology
@@ -49,14 +50,27 @@ def main():
     ws = workspace(wsb, dev)
     st = torch.cuda.current_stream(dev).cuda_stream
 
+    use_signs = bool(args.signs and args.relu and Cout % 4 == 0 and K > 1)
+    signs = torch.empty(B, N, max(Cout // 4, 1), dtype=torch.uint8, device=dev)
+
     def fwd():
-        check(L.mvh_cheb_conv_fwd(st, op.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None,
-                                  B, N, Cin, Cout, K, args.relu, ws.data_ptr(), wsb))
+        if use_signs:
+            check(L.mvh_cheb_conv_fwd_signs(st, op.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                            signs.data_ptr(), B, N, Cin, Cout, K, ws.data_ptr(), wsb))
+        else:
+            check(L.mvh_cheb_conv_fwd(st, op.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None,
+                                      B, N, Cin, Cout, K, args.relu, ws.data_ptr(), wsb))
 
     def bwd():
-        check(L.mvh_cheb_conv_bwd(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                  dout.data_ptr(), None, None if args.dwonly else dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                                  B, N, Cin, Cout, K, args.relu, ws.data_ptr(), wsb))
+        dxp = None if args.dwonly else dx.data_ptr()
+        if use_signs:
+            check(L.mvh_cheb_conv_bwd_signs(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                            signs.data_ptr(), dout.data_ptr(), dxp, dW.data_ptr(), db.data_ptr(),
+                                            B, N, Cin, Cout, K, ws.data_ptr(), wsb))
+        else:
+            check(L.mvh_cheb_conv_bwd(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                      dout.data_ptr(), None, dxp, dW.data_ptr(), db.data_ptr(),
+                                      B, N, Cin, Cout, K, args.relu, ws.data_ptr(), wsb))
 
     fn = bwd if (args.bwd or args.dwonly) else fwd
     fwd()
