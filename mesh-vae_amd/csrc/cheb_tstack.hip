@@ -1,0 +1,259 @@
+// First-layer weight gradient through a saved Chebyshev stack.
+//
+// cheb.0 of the VAE (cheb_VAE.py:264) reads the 3-channel input mesh and is followed by the one-hot
+// downsampling D, so the gradient of its output is non-zero only at the n_sel rows D selects
+// (1250 of 4998).  Its weight gradient
+//     dW_k[ci][co] = sum_{b,v} T_k(L) x [b,v,ci] * dpre[b,v,co]
+// therefore needs T_k(L) x only at those rows.  Two kernels:
+//   k_cheb_tstack : ONE workgroup per mesh runs the K-order recurrence on the (<= 4 channel) input in
+//                   the 160 KB LDS image of the other LDS kernels and stores T_k x of every vertex:
+//                   stack [B][N+1][K][4] (row N collects the padding slots; storing only the selected
+//                   rows needs a divergent store per vertex and order, which cost 214 spilled VGPRs).
+//                   64 workgroups: it leaves 3/4 of the chip to the small kernels of the main chain,
+//                   which is where the step engine schedules it.
+//   k_stack_dw    : streaming reduction  stack^T * (dout masked by the ReLU sign bytes)  over the
+//                   B * n_sel rows (fixed order: per-block partials + one finishing block).
+// Replaces the LDS-resident dW kernel for this layer (4 workgroups per mesh each re-running the
+// recurrence, 64 + 5 us at the end of the backward critical path) by a 5 us reduction.
+#include "common.hpp"
+
+namespace mvh {
+
+struct TstackDims {
+  int B, N, K, Cin, n_sel;
+};
+
+template <int VPT, int TCT, int PW>
+__global__ void __launch_bounds__(TCT)
+k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowinfo, const uint32_t* __restrict__ p_ell,
+              float* __restrict__ p_stack, TstackDims a) {
+  constexpr int THREADS = TCT, VS = VPT * THREADS;
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* slab = reinterpret_cast<float4*>(smem);     // [VS] scaled t~_k = D^-1/2 T_k x; rows >= N stay zero
+  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]
+  const int mesh = blockIdx.x, tid = threadIdx.x, N = a.N;
+  {
+    const unsigned pad = (unsigned)N | ((unsigned)N << 16);
+    const uint4 pad4 = make_uint4(pad, pad, pad, pad);
+    const uint4* src = reinterpret_cast<const uint4*>(p_ell);
+    for (int i = tid; i < VS * (PW / 4); i += THREADS) ellv[i] = (i / (PW / 4) < N) ? src[i] : pad4;
+  }
+  float ka2[VPT], inv_s[VPT];
+  float4 R[VPT];
+  float* const sbase = p_stack + (long long)mesh * (N + 1) * a.K * 4;
+  const float* xb = p_x + (long long)mesh * N * a.Cin;
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) {
+    const int v = tid + vi * THREADS;
+    const bool valid = v < N;
+    const int vl = min(v, N - 1);
+    const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
+    ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+    const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    inv_s[vi] = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < a.Cin) t[c] = xb[(long long)vl * a.Cin + c];
+    if (!valid) t[0] = t[1] = t[2] = t[3] = 0.f;
+    *reinterpret_cast<float4*>(sbase + (long long)min(v, N) * a.K * 4) = make_float4(t[0], t[1], t[2], t[3]);  // T_0 x = x
+    slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);
+    R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  auto add4 = [](float4& x, const float4& y) {
+    x.x += y.x;
+    x.y += y.y;
+    x.z += y.z;
+    x.w += y.w;
+  };
+  auto gather = [&](int v) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < PW / 4; ++q) {
+      const uint4 id = ellv[v * (PW / 4) + q];
+      {
+        const float4 n0 = slab[id.x & 0xffffu], n1 = slab[id.x >> 16];
+        const float4 n2 = slab[id.y & 0xffffu], n3 = slab[id.y >> 16];
+        add4(g, n0); add4(g, n1); add4(g, n2); add4(g, n3);
+      }
+      asm volatile("" ::: "memory");
+      {
+        const float4 n0 = slab[id.z & 0xffffu], n1 = slab[id.z >> 16];
+        const float4 n2 = slab[id.w & 0xffffu], n3 = slab[id.w >> 16];
+        add4(g, n0); add4(g, n1); add4(g, n2); add4(g, n3);
+      }
+      asm volatile("" ::: "memory");
+    }
+    return g;
+  };
+  for (int k = 1; k < a.K; ++k) {
+    const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const float4 g = gather(tid + vi * THREADS);
+      const float kk = ka2[vi] * sc;
+      R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
+                          fmaf(kk, g.w, -R[vi].w));
+    }
+    __syncthreads();  // every gather of t~_{k-1} is done
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      const float4 old = slab[v];
+      const float4 cur = R[vi];
+      slab[v] = cur;
+      R[vi] = old;
+      *reinterpret_cast<float4*>(sbase + ((long long)min(v, N) * a.K + k) * 4) =
+          make_float4(cur.x * inv_s[vi], cur.y * inv_s[vi], cur.z * inv_s[vi], cur.w * inv_s[vi]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- dW / db from the stack: out[k][ci][co] = sum_rows stack[row][k][ci] * dpre[row][co]
+constexpr int kSdwRows = 64;    // rows per LDS tile
+constexpr int kSdwGrid = 128;
+
+struct SdwDims {
+  int rows, n_sel, N, K, Cin, Cout;
+};
+
+__global__ void __launch_bounds__(512)
+k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, const uint8_t* __restrict__ bits,
+           const float* __restrict__ out_mask, const int* __restrict__ sel_col, float* __restrict__ partial,
+           SdwDims a) {
+  // dpre[row][co] = dout[row][co] where the forward output at the row's fine vertex is > 0
+  __shared__ float sA[kSdwRows][36];  // [row][k*4 + ci], K <= 8 (+4: bank spread, keeps 16-byte alignment)
+  __shared__ float sB[kSdwRows][36];  // [row][co], Cout <= 32
+  const int n_w = a.K * a.Cin * a.Cout, n_out = n_w + a.Cout;
+  const int t = threadIdx.x, ty = t >> 3, tx = t & 7;  // tile loads: 8 lanes per row, one float4 each
+  const int rpb = (a.rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(a.rows, r0 + rpb);
+  // thread t < n_w owns dW entry (k, ci, co); n_w <= t < n_out owns db[co]
+  const int co = t < n_w ? t % a.Cout : t - n_w;
+  const int kc = t < n_w ? (t / a.Cout / a.Cin) * 4 + (t / a.Cout) % a.Cin : 0;
+  const int CQ4 = a.Cout >> 2;
+  float acc = 0.f;
+  for (int base = r0; base < r1; base += kSdwRows) {
+    const int nr = min(kSdwRows, r1 - base);
+    if (ty < nr) {
+      const int r = base + ty, b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
+      if (tx < a.K)
+        *reinterpret_cast<float4*>(&sA[ty][tx * 4]) =
+            *reinterpret_cast<const float4*>(stack + (((long long)b * (a.N + 1) + v) * a.K + tx) * 4);
+      if (tx < CQ4) {
+        float4 d = *reinterpret_cast<const float4*>(dout + (long long)r * a.Cout + tx * 4);
+        if (bits) {
+          const uint32_t m = bits[((long long)b * a.N + v) * CQ4 + tx];
+          d.x = (m & 1u) ? d.x : 0.f;
+          d.y = (m & 2u) ? d.y : 0.f;
+          d.z = (m & 4u) ? d.z : 0.f;
+          d.w = (m & 8u) ? d.w : 0.f;
+        } else if (out_mask) {
+          const float4 o = *reinterpret_cast<const float4*>(out_mask + ((long long)b * a.N + v) * a.Cout + tx * 4);
+          d.x = o.x > 0.f ? d.x : 0.f;
+          d.y = o.y > 0.f ? d.y : 0.f;
+          d.z = o.z > 0.f ? d.z : 0.f;
+          d.w = o.w > 0.f ? d.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(&sB[ty][tx * 4]) = d;
+      }
+    }
+    __syncthreads();
+    if (t < n_w) {
+      float a0 = 0.f, a1 = 0.f;
+      int r = 0;
+      for (; r + 1 < nr; r += 2) {
+        a0 = fmaf(sA[r][kc], sB[r][co], a0);
+        a1 = fmaf(sA[r + 1][kc], sB[r + 1][co], a1);
+      }
+      if (r < nr) a0 = fmaf(sA[r][kc], sB[r][co], a0);
+      acc += a0 + a1;
+    } else if (t < n_out) {
+      float a0 = 0.f;
+      for (int r = 0; r < nr; ++r) a0 += sB[r][co];
+      acc += a0;
+    }
+    __syncthreads();
+  }
+  if (t < n_out) partial[(long long)blockIdx.x * n_out + t] = acc;
+}
+
+__global__ void __launch_bounds__(1024)
+k_stack_dw_finish(const float* __restrict__ partial, int nblocks, int n_w, int n_out, float* __restrict__ dW,
+                  float* __restrict__ db) {
+  // group g of 1024 / n_out sums blocks g, g + G, ... with 4 independent chains; groups combined in order
+  __shared__ float red[1024];
+  const int G = 1024 / n_out;
+  const int g = threadIdx.x / n_out, e = threadIdx.x - g * n_out;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (g < G) {
+    int b = g;
+    for (; b + 3 * G < nblocks; b += 4 * G) {
+      s0 += partial[(long long)b * n_out + e];
+      s1 += partial[(long long)(b + G) * n_out + e];
+      s2 += partial[(long long)(b + 2 * G) * n_out + e];
+      s3 += partial[(long long)(b + 3 * G) * n_out + e];
+    }
+    for (; b < nblocks; b += G) s0 += partial[(long long)b * n_out + e];
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if ((int)threadIdx.x >= n_out) return;
+  float s = 0.f;
+  for (int k = 0; k < G; ++k) s += red[k * n_out + threadIdx.x];
+  if ((int)threadIdx.x < n_w) dW[threadIdx.x] = s;  // [k][ci][co] is the thread order
+  else if (db) db[threadIdx.x - n_w] = s;
+}
+
+// workspace: the stack [B][N+1][K][4], then the per-block partials of the reduction
+size_t tstack_stack_floats(int B, int N, int K) { return (size_t)B * (N + 1) * K * 4; }
+size_t tstack_ws_floats(int B, int N, int K, int Cin, int Cout) {
+  return tstack_stack_floats(B, N, K) + (size_t)kSdwGrid * ((size_t)K * Cin * Cout + Cout) + 64;
+}
+
+bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K) {
+  const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
+  if (!lap || !pool || !lap->rowinfo || !lap->ell || (lap->flags & need) != need) return false;
+  if (lap->ell_pairs <= 0 || lap->ell_pairs > 8) return false;
+  if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0) return false;
+  if (Cin < 1 || Cin > 4 || Cout < 4 || Cout > 32 || Cout % 4 != 0 || K < 1 || K > 8) return false;
+  if (K * Cin * Cout + Cout > 512) return false;
+  if (N + 1 <= 2048 || N + 1 > 5120) return false;  // only the 160 KB configuration pays: smaller levels keep the LDS dW kernel
+  const int pw = lap->ell_pairs > 4 ? 8 : 4;
+  if ((size_t)5120 * (16 + pw * 4) > 160 * 1024) return false;
+  return true;
+}
+
+// stack [B][N+1][K][4] <- T_k(L) x
+int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
+                  int N, int Cin, int K) {
+  TstackDims d{B, N, K, Cin, pool->n_rows};
+  const size_t lds = (size_t)5120 * (16 + 4 * 4);
+  auto kern = k_cheb_tstack<10, 512, 4>;  // 256 VGPRs per lane: the 1024 x 5 shape spilled 86 of its 128
+  static bool attr = false;
+  if (!attr) {
+    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, st, x, lap->rowinfo, lap->ell, stack, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// dW [K][Cin][Cout], db [Cout] from the stack and the gradient of the POOLED output dout [B][n_sel][Cout]
+int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,
+                    const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K) {
+  SdwDims d{B * pool->n_rows, pool->n_rows, N, K, Cin, Cout};
+  const int n_w = K * Cin * Cout, n_out = n_w + Cout;
+  int grid = (d.rows + kSdwRows - 1) / kSdwRows;
+  if (grid > kSdwGrid) grid = kSdwGrid;
+  hipLaunchKernelGGL(k_stack_dw, dim3(grid), dim3(512), 0, st, stack, dout, bits, out_mask, pool->col, partial, d);
+  MVH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_stack_dw_finish, dim3(1), dim3(1024), 0, st, partial, grid, n_w, n_out, dW, db);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+}  // namespace mvh

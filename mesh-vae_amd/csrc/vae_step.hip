@@ -26,6 +26,7 @@ struct StepPlan {
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
   std::vector<size_t> dwPartEnc, dwPartDec;  // per-layer dW partial tiles (reduced together after the join)
   std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
+  size_t tstack;                         // T_k x of layer 0 at the rows its pooling selects (+ dW partials)
   size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   size_t total;
@@ -87,6 +88,7 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
   p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
   p.weff_final = take(cur, (size_t)p.f[1] * p.f[0]);
+  p.tstack = take(cur, tstack_ws_floats(B, p.Nn[0], d->K[0], p.f[0], p.f[1]));
   p.dwPartEnc.resize(n); p.dwPartDec.resize(n); p.dwPartBytesEnc.resize(n); p.dwPartBytesDec.resize(n);
   for (int i = 0; i < n; ++i) {
     p.dwPartBytesEnc[i] = cheb_dw_lds_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]);
@@ -283,6 +285,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
   const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
+  const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
+                          d->down[0].n_rows == p.Nn[1] && !getenv("MESHVAE_NO_TSTACK");
+  hipEvent_t ev_tstack = nullptr;
+  static const char* tail_env = getenv("MESHVAE_TAIL_MAIN");
+  const bool tail_on_main = use_tstack && sstream != main && !(tail_env && tail_env[0] == '0');
   DwReduceTable red;        // pending dW reductions: one launch after the join
   red.n = 0;
   // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists.
@@ -377,6 +384,16 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]),
                      p.dwPartDec[i], p.dwPartBytesDec[i]));
+    if (i == n - 1 && use_tstack) {
+      // T_k x of encoder layer 0 at its pooled rows: 64 workgroups on the side lane behind the (chip-filling)
+      // dW above, i.e. while the main chain runs its small-level kernels; consumed at the very end
+      TRY(launch_tstack(sstream, &d->lap[0], &d->down[0], x, F(p.tstack), B, p.Nn[0], p.f[0], d->K[0]));
+      if (sstream != main) {
+        MVH_HIP(hipEventRecord(side->ev[ev], sstream));
+        ev_tstack = side->ev[ev];
+        ev = (ev + 1) % side->n_ev;
+      }
+    }
     // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
@@ -416,7 +433,10 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   for (int i = n - 1; i >= 0; --i) {
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
     if (i > 0) {
-      // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible)
+      // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible);
+      // with the stack path layer 0 costs the main stream only ~10 us, so layer 1's dW runs there after it
+      // instead of at the end of the side lane's backlog (MESHVAE_TAIL_MAIN=0: side lane as usual)
+      if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
                        p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i])));
@@ -437,6 +457,29 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     // latency, no queueing behind the side lane).  Everything still queued is forked FIRST, or it
     // would wait behind this kernel.
     TRY(flush_dw(false));
+    if (use_tstack) {  // dW_0 = stack^T dpre over the pooled rows only: a 5 us streaming reduction
+      if (ev_tstack) MVH_HIP(hipStreamWaitEvent(main, ev_tstack, 0));
+      TRY(launch_stack_dw(main, &d->down[0], F(p.tstack), F(p.g_encP[0]), BITS(p.encBits[0]), F(p.encA[0]),
+                          G[ix.encW(0)], G[ix.encB(0)], F(p.tstack) + tstack_stack_floats(B, p.Nn[0], d->K[0]), B, p.Nn[0],
+                          p.f[0], p.f[1], d->K[0]));
+      if (tail_on_main && n > 1) {
+        bool fused = false, dfr = false;
+        const float* xin1 = F(p.encP[0]);
+        TRY(cheb_conv_bwd_impl(main, &d->lap[1], &d->lap_t[1], xin1, P[ix.encW(1)], F(p.encA[1]), F(p.g_encP[1]), nullptr,
+                               nullptr, G[ix.encW(1)], G[ix.encB(1)], B, p.Nn[1], p.f[1], p.f[2], d->K[1], MVH_ACT_RELU, sm,
+                               p.scratch_bytes, nullptr, &d->down[1], &fused, BITS(p.encBits[1]), nullptr, &red.e[red.n],
+                               F(p.dwPartEnc[1]), p.dwPartBytesEnc[1], &dfr));
+        if (!fused) {
+          TRY(mvh_pool_bwd(stream, &d->down_t[1], F(p.g_encP[1]), F(p.g_encA[1]), B, p.f[2]));
+          TRY(cheb_conv_bwd_impl(main, &d->lap[1], &d->lap_t[1], xin1, P[ix.encW(1)], F(p.encA[1]), F(p.g_encA[1]),
+                                 nullptr, nullptr, G[ix.encW(1)], G[ix.encB(1)], B, p.Nn[1], p.f[1], p.f[2], d->K[1],
+                                 MVH_ACT_RELU, sm, p.scratch_bytes, nullptr, nullptr, nullptr, BITS(p.encBits[1]), nullptr,
+                                 &red.e[red.n], F(p.dwPartEnc[1]), p.dwPartBytesEnc[1], &dfr));
+        }
+        if (dfr) ++red.n;
+      }
+      continue;
+    }
     bool ok_dw = false, deferred = false;
     TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]), nullptr,
                            nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
