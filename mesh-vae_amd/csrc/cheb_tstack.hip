@@ -112,55 +112,66 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
 }
 
 // ---- dW / db from the stack: out[k][ci][co] = sum_rows stack[row][k][ci] * dpre[row][co]
-constexpr int kSdwRows = 64;    // rows per LDS tile
-constexpr int kSdwGrid = 128;
+constexpr int kSdwGrid = 256;
 
 struct SdwDims {
   int rows, n_sel, N, K, Cin, Cout;
 };
 
+constexpr int kSdwRows = 64;  // rows per LDS tile
+
 __global__ void __launch_bounds__(512)
 k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, const uint8_t* __restrict__ bits,
            const float* __restrict__ out_mask, const int* __restrict__ sel_col, float* __restrict__ partial,
            SdwDims a) {
-  // dpre[row][co] = dout[row][co] where the forward output at the row's fine vertex is > 0
+  // dpre[row][co] = dout[row][co] where the forward output at the row's fine vertex is > 0.
+  // Tiles of 64 rows go through LDS (8 lanes per row, one float4 each; the next tile's loads are
+  // issued before the current tile is consumed); thread t < n_w owns dW entry (k, ci, co) and
+  // n_w <= t < n_out owns db[co].  (A barrier-free variant with wave-uniform rows and broadcast loads
+  // was 2-3x slower: 6 dependent small loads per row and lane.)
   __shared__ float sA[kSdwRows][36];  // [row][k*4 + ci], K <= 8 (+4: bank spread, keeps 16-byte alignment)
   __shared__ float sB[kSdwRows][36];  // [row][co], Cout <= 32
   const int n_w = a.K * a.Cin * a.Cout, n_out = n_w + a.Cout;
-  const int t = threadIdx.x, ty = t >> 3, tx = t & 7;  // tile loads: 8 lanes per row, one float4 each
+  const int t = threadIdx.x, ty = t >> 3, tx = t & 7;
   const int rpb = (a.rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rpb, r1 = min(a.rows, r0 + rpb);
-  // thread t < n_w owns dW entry (k, ci, co); n_w <= t < n_out owns db[co]
   const int co = t < n_w ? t % a.Cout : t - n_w;
   const int kc = t < n_w ? (t / a.Cout / a.Cin) * 4 + (t / a.Cout) % a.Cin : 0;
   const int CQ4 = a.Cout >> 2;
+  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+  auto fetch = [&](int base) {  // this thread's pieces of the tile starting at `base`, into registers
+    pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    pb = pa;
+    const int r = base + ty;
+    if (r >= r1) return;
+    const int b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
+    if (tx < a.K) pa = *reinterpret_cast<const float4*>(stack + (((long long)b * (a.N + 1) + v) * a.K + tx) * 4);
+    if (tx < CQ4) {
+      float4 d = *reinterpret_cast<const float4*>(dout + (long long)r * a.Cout + tx * 4);
+      if (bits) {
+        const uint32_t m = bits[((long long)b * a.N + v) * CQ4 + tx];
+        d.x = (m & 1u) ? d.x : 0.f;
+        d.y = (m & 2u) ? d.y : 0.f;
+        d.z = (m & 4u) ? d.z : 0.f;
+        d.w = (m & 8u) ? d.w : 0.f;
+      } else if (out_mask) {
+        const float4 o = *reinterpret_cast<const float4*>(out_mask + ((long long)b * a.N + v) * a.Cout + tx * 4);
+        d.x = o.x > 0.f ? d.x : 0.f;
+        d.y = o.y > 0.f ? d.y : 0.f;
+        d.z = o.z > 0.f ? d.z : 0.f;
+        d.w = o.w > 0.f ? d.w : 0.f;
+      }
+      pb = d;
+    }
+  };
   float acc = 0.f;
+  fetch(r0);
   for (int base = r0; base < r1; base += kSdwRows) {
     const int nr = min(kSdwRows, r1 - base);
-    if (ty < nr) {
-      const int r = base + ty, b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
-      if (tx < a.K)
-        *reinterpret_cast<float4*>(&sA[ty][tx * 4]) =
-            *reinterpret_cast<const float4*>(stack + (((long long)b * (a.N + 1) + v) * a.K + tx) * 4);
-      if (tx < CQ4) {
-        float4 d = *reinterpret_cast<const float4*>(dout + (long long)r * a.Cout + tx * 4);
-        if (bits) {
-          const uint32_t m = bits[((long long)b * a.N + v) * CQ4 + tx];
-          d.x = (m & 1u) ? d.x : 0.f;
-          d.y = (m & 2u) ? d.y : 0.f;
-          d.z = (m & 4u) ? d.z : 0.f;
-          d.w = (m & 8u) ? d.w : 0.f;
-        } else if (out_mask) {
-          const float4 o = *reinterpret_cast<const float4*>(out_mask + ((long long)b * a.N + v) * a.Cout + tx * 4);
-          d.x = o.x > 0.f ? d.x : 0.f;
-          d.y = o.y > 0.f ? d.y : 0.f;
-          d.z = o.z > 0.f ? d.z : 0.f;
-          d.w = o.w > 0.f ? d.w : 0.f;
-        }
-        *reinterpret_cast<float4*>(&sB[ty][tx * 4]) = d;
-      }
-    }
+    if (tx < a.K) *reinterpret_cast<float4*>(&sA[ty][tx * 4]) = pa;
+    if (tx < CQ4) *reinterpret_cast<float4*>(&sB[ty][tx * 4]) = pb;
     __syncthreads();
+    fetch(base + kSdwRows);  // in flight while this tile is consumed
     if (t < n_w) {
       float a0 = 0.f, a1 = 0.f;
       int r = 0;
