@@ -45,6 +45,19 @@ def model_5k_npz():
     return load_golden("model_5k.npz")
 
 
+@pytest.fixture(scope="session")
+def topo20k_npz():
+    return load_golden("topology_20k.npz")
+
+
+@pytest.fixture(scope="session")
+def model_20k_npz():
+    return load_golden("model_20k.npz")
+
+
+# BASELINE configs[3] as SURVEY 8(d) pins it: 1->4 subdivision of the 5k template, 6 levels, K = 10
+CFG_20K = {"n_layers": 5, "num_conv_filters": [16, 16, 16, 32, 32, 32], "polygon_order": [10] * 6,
+           "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
 TINY_CFG = {"n_layers": 2, "num_conv_filters": [8, 16, 16], "polygon_order": [6, 6, 6],
             "num_classes": 2, "num_style": 16, "num_hidden": 64, "dropout": 0.2}
 CFG_5K = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_order": [6, 6, 6, 6, 6],

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, ROOT, TINY_CFG, state_dict_from
+from conftest import CFG_5K, CFG_20K, ROOT, TINY_CFG, state_dict_from
 
 pytestmark = pytest.mark.gpu
 FWD_ATOL = 1e-4
@@ -271,6 +271,50 @@ def test_full_model_eval_matches_reference(which, model_tiny_npz, model_5k_npz):
     assert int(correct) == int(npz["eval/correct"]) and correct.dtype == torch.int64
     l2 = (recon.cpu() - _t(npz["eval/recon"])).pow(2).sum().sqrt().item()
     print(f"[{which}] recon L2 vs reference = {l2:.3e}, max|d| = {(recon.cpu() - _t(npz['eval/recon'])).abs().max():.3e}")
+
+
+def test_hires_20k_config_matches_reference(model_20k_npz):
+    """BASELINE configs[3]: 19 992-vertex template, 6 levels, K = 10 everywhere (level 0 runs through the
+    general pipeline, the 5k level and below through the LDS-resident kernels with K = 10) against
+    vectors captured from the reference at B = 2: eval forward, then train-mode loss and gradients."""
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    npz, dev = model_20k_npz, _dev()
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_20k.npz"), dev)
+    B = 2
+    x = torch.randn(B, 19992, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, num_classes=2).to(dev)
+    torch.manual_seed(666)
+    net = cheb_VAE(3, CFG_20K, D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
+    assert [str(k) for k in npz["sd_keys"]] == list(net.state_dict().keys())
+    assert torch.equal(net.state_dict()["cheb.0.weight"].reshape(-1)[:64].cpu(), _t(npz["sd_head/cheb.0.weight"]))
+    net.eval()
+    with torch.no_grad():
+        loss, correct, recon, (kld, rec, z_), y_hat = net(_Data(x), x.clone(), y, m_type="test")
+    A_ = FWD_ATOL
+    torch.testing.assert_close(y_hat.cpu(), _t(npz["eval/y_hat"]), rtol=0, atol=A_)
+    torch.testing.assert_close(z_.cpu(), _t(npz["eval/z"]), rtol=0, atol=A_)
+    torch.testing.assert_close(kld.cpu(), _t(npz["eval/kld"]), rtol=0, atol=A_)
+    torch.testing.assert_close(recon[:, :512].cpu(), _t(npz["eval/recon_head"]), rtol=0, atol=A_)
+    torch.testing.assert_close(recon[:, -512:].cpu(), _t(npz["eval/recon_tail"]), rtol=0, atol=A_)
+    assert abs(float(recon.double().sum()) - float(npz["eval/recon_sum"])) < 1e-4 * float(npz["eval/recon_abs_sum"])
+    torch.testing.assert_close(loss.cpu(), _t(npz["eval/loss"]), rtol=2e-6, atol=5e-2)
+    torch.manual_seed(666)
+    net = cheb_VAE(3, dict(CFG_20K, dropout=0.0), D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
+    net.train()
+    torch.manual_seed(123)
+    loss, correct, recon, (kld, rec, z_), y_hat = net(_Data(x), x.double(), y, m_type="train")
+    loss.backward()
+    assert loss.dtype == torch.float64
+    torch.testing.assert_close(loss.detach().cpu(), _t(npz["train/loss"]), rtol=1e-7, atol=1e-2)
+    names = [str(n) for n in npz["train/grad_names"]]
+    got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(names)
+    for k in names:
+        gn = float(npz[f"train/gnorm/{k}"])
+        assert abs(float(got[k].double().norm()) - gn) <= 2e-4 * gn + 1e-7, (k, float(got[k].double().norm()), gn)
+        torch.testing.assert_close(got[k].reshape(-1)[:1024].cpu(), _t(npz[f"train/grad_head/{k}"]), rtol=1e-3,
+                                   atol=2e-4 * max(gn / max(got[k].numel() ** 0.5, 1.0), 1e-3), msg=k)
 
 
 @pytest.mark.parametrize("which", ["tiny", "5k"])

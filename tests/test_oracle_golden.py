@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, TINY_CFG, state_dict_from
+from conftest import CFG_5K, CFG_20K, TINY_CFG, state_dict_from
 from oracle import cheb_oracle as O
 
 
@@ -141,3 +141,44 @@ def test_full_model_eval_and_train(which, model_tiny_npz, model_5k_npz, topotiny
     assert "dec_lin_1.weight" not in g                         # never used (cheb_VAE.py:165)
     for name, grad in g.items():
         torch.testing.assert_close(grad, _t(npz[f"train/grad/{name}"]), rtol=1e-4, atol=1e-5, msg=name)
+
+
+def test_hires_20k_config_oracle_matches_reference(topo20k_npz, model_20k_npz):
+    """BASELINE configs[3] (19 992-vertex template, 6 levels, K = 10): constructor RNG order, eval
+    forward and the train-mode loss/gradients of the oracle against vectors captured from the
+    reference (oracle/make_golden_20k.py); weights are not stored, they come from the seed."""
+    npz = model_20k_npz
+    assert list(topo20k_npz["num_nodes"]) == [19992, 4998, 1250, 313, 79, 20]
+    topo = O.Topology(topo20k_npz)
+    torch.manual_seed(666)
+    sd = O.init_state_dict(CFG_20K, topo)
+    assert [str(k) for k in npz["sd_keys"]] == list(sd.keys())
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(npz["sd_abs_sum"])) < 1e-6 * float(npz["sd_abs_sum"])
+    assert torch.equal(sd["cheb.0.weight"].reshape(-1)[:64], _t(npz["sd_head/cheb.0.weight"]))
+    assert torch.equal(sd["dec_lin_2.weight"].reshape(-1)[:64], _t(npz["sd_head/dec_lin_2.weight"]))
+    B = 2
+    x = torch.randn(B, 19992, 3, generator=torch.Generator().manual_seed(0))
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, num_classes=2)
+    net = O.OracleVAE(CFG_20K, topo, sd)
+    with torch.no_grad():
+        loss, correct, recon, (k, rec, z_), y_hat, mu, logvar = net.forward(x, x.clone(), y, "test")
+    torch.testing.assert_close(y_hat, _t(npz["eval/y_hat"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(z_, _t(npz["eval/z"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(k, _t(npz["eval/kld"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(recon[:, :512], _t(npz["eval/recon_head"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(recon[:, -512:], _t(npz["eval/recon_tail"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss, _t(npz["eval/loss"]), rtol=1e-6, atol=5e-2)
+    net = O.OracleVAE(dict(CFG_20K, dropout=0.0), topo, sd, requires_grad=True)
+    net.training = True
+    torch.manual_seed(123)
+    loss, *_ = net.forward(x, x.double(), y, "train")
+    loss.backward()
+    assert loss.dtype == torch.float64
+    torch.testing.assert_close(loss.detach(), _t(npz["train/loss"]), rtol=1e-9, atol=1e-3)
+    g = net.grads()
+    assert set(g) == set(str(n) for n in npz["train/grad_names"])
+    for name, grad in g.items():
+        gn = float(npz[f"train/gnorm/{name}"])
+        assert abs(float(grad.double().norm()) - gn) <= 1e-4 * gn + 1e-7, name
+        torch.testing.assert_close(grad.reshape(-1)[:1024], _t(npz[f"train/grad_head/{name}"]), rtol=1e-3,
+                                   atol=1e-4 * max(gn / max(grad.numel() ** 0.5, 1.0), 1e-3), msg=name)
