@@ -311,17 +311,25 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       }
       return;
     }
+    // all cross-lane sums first (independent chains), then ONE predicated block of stores
+    float red[QH][4][4];
 #pragma unroll
     for (int h = 0; h < QH; ++h)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[h][m][r];
-          x = sum_blocks(x);
-          const int q = 16 * h + 4 * r + m;
-          if (lane < 4 && q < CQ) part[((long long)k * CQT + q) * 4 + lane] = x;
-        }
+        for (int r = 0; r < 4; ++r) red[h][m][r] = sum_blocks(acc[h][m][r]);
+    if (lane < 4) {
+#pragma unroll
+      for (int h = 0; h < QH; ++h)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * h + 4 * r + m;
+            if (q < CQ) part[((long long)k * CQT + q) * 4 + lane] = red[h][m][r];
+          }
+    }
   };
 
   mfma_pass(0);
