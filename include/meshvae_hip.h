@@ -53,7 +53,10 @@ typedef struct mvh_csr {
    * column list in padded ELL form, two uint16 columns per word, vertex-major:
    * ell[r * PW + p] = col(r, 2p) | col(r, 2p+1) << 16 with PW = 4 words per row when
    * ell_pairs <= 4, else 8; out-of-row slots are set to n_cols (an all-zero dummy row the
-   * kernels keep in LDS).  The kernels copy it to LDS with 16-byte loads. */
+   * kernels keep in LDS).  The kernels copy it to LDS with 16-byte loads.
+   * With MVH_CSR_ELL_OVERFLOW the list holds only the FIRST 8 columns of a row (ell_pairs = 4) and
+   * rows with 9..12 entries continue in col[rowptr[r] + 8 ..]: a decimated level has 2-6 % of such
+   * vertices, which would otherwise double the padded width (and the LDS gather work) for everyone. */
   const uint32_t* rowinfo; /* [n_rows] device */
   const uint32_t* ell;     /* [n_rows * PW] device, 16-byte aligned */
   int32_t ell_pairs;       /* ceil(max_row_nnz / 2) */
@@ -78,6 +81,7 @@ typedef struct mvh_csr {
 /* the operator equals its transpose (same pattern, same values) */
 #define MVH_CSR_SYMMETRIC 2
 #define MVH_CSR_SELECTION 4
+#define MVH_CSR_ELL_OVERFLOW 8
 
 int mvh_version(void);
 const char* mvh_last_error(void);

@@ -30,6 +30,7 @@ struct DwDims {
   int map_side, map_bs;                    // fused un-pooling of dout: 1 = P rows, 2 = Q rows come through p_map
                                            // from a compact buffer of map_bs rows per mesh (masks stay full-size)
   int mask_bits;                           // the mask pointer holds ReLU sign bytes (one per vertex and 4 channels)
+  int ovf;                                 // MVH_CSR_ELL_OVERFLOW: rows longer than 8 continue in the CSR columns
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
               const float* __restrict__ p_Qmask, const uint32_t* __restrict__ p_rowinfo,
               const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, const int32_t* __restrict__ p_map,
-              DwDims a) {
+              const int* __restrict__ p_col, DwDims a) {
   // CQ % 8 == 0: the workgroup holds all CQ channels of Q (16 per float4-per-lane register group);
   // CQ == 4   : "Q-split" mode for P sides of <= 4 channels (cheb.0 and the final layer): the
   //             a.CQtot channels of Q are split over CQtot/4 workgroups (one channel per lane,
@@ -183,6 +184,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   // ---- own vertices (thread-owns-vertex layout): t~_0 = s P[:, slab]
   float ka2[VPT];
   float4 R[VPT];
+  constexpr bool kOvf = (TCT == 0);  // columns 8..11 of long rows (see cheb_lds.hip), small levels only
+  uint32_t ovf0[kOvf ? VPT : 1], ovf1[kOvf ? VPT : 1];
+  bool ovf_any[kOvf ? VPT : 1];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Pb = p_P + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
   const float* Pm = (p_Pmask && !a.mask_bits) ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
@@ -194,9 +198,23 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     const int v = tid + vi * THREADS;
     const bool valid = v < N;
     const int vl = min(v, N - 1);
-    const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
+    const uint32_t rinfo = p_rowinfo[vl];
+    const float deg = valid ? (float)(rinfo & 255u) : 0.f;
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    if constexpr (kOvf) {
+      const unsigned padw = (unsigned)N | ((unsigned)N << 16);
+      ovf0[vi] = ovf1[vi] = padw;
+      const int dg = valid ? (int)(rinfo & 255u) : 0;
+      ovf_any[vi] = a.ovf && dg > 8;
+      if (ovf_any[vi]) {
+        const int* cp = p_col + (rinfo >> 8) + 8;
+        const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
+        const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
+        ovf0[vi] = c0 | (c1 << 16);
+        ovf1[vi] = c2 | (c3 << 16);
+      }
+    }
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     int pl = vl;
     bool phave = true;
@@ -255,7 +273,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   }
   __syncthreads();  // slab = t~_0, ELL staged
 
-  auto gather = [&](int v) {
+  auto gather = [&](int v, int vi) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < PW / 4; ++q) {
@@ -272,6 +290,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         add4f(g, n0); add4f(g, n1); add4f(g, n2); add4f(g, n3);
       }
       asm volatile("" ::: "memory");
+    }
+    if constexpr (kOvf) {
+      if (ovf_any[vi]) {
+        const float4 n0 = slab[ovf0[vi] & 0xffffu], n1 = slab[ovf0[vi] >> 16];
+        const float4 n2 = slab[ovf1[vi] & 0xffffu], n3 = slab[ovf1[vi] >> 16];
+        add4f(g, n0); add4f(g, n1); add4f(g, n2); add4f(g, n3);
+      }
     }
     return g;
   };
@@ -337,7 +362,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
-      const float4 g = gather(tid + vi * THREADS);
+      const float4 g = gather(tid + vi * THREADS, vi);
       const float kk = ka2[vi] * sc;
       R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
                           fmaf(kk, g.w, -R[vi].w));
@@ -439,7 +464,7 @@ static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const 
   }
   const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
   const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, d);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -487,7 +512,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   int vpt, threads;
   if (N + 1 <= 1024) { vpt = 1; threads = ((N + 1 + 63) / 64) * 64; }
   else if (N + 1 <= 2048) { vpt = 2; threads = (((N + 2) / 2 + 63) / 64) * 64; }
-  else if (N + 1 <= 5120 && CQ <= 16) { vpt = 10; threads = 512; }
+  else if (N + 1 <= 5120 && CQ <= 16 && !(lap->flags & MVH_CSR_ELL_OVERFLOW)) { vpt = 10; threads = 512; }
   else return MVH_OK;
   const int pw = lap->ell_pairs > 4 ? 8 : 4;
   if ((size_t)vpt * threads * (16 + pw * 4) > 160 * 1024) return MVH_OK;
@@ -502,6 +527,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   }
   DwDims d;
   d.mask_bits = out_bits ? 1 : 0;
+  d.ovf = (lap->flags & MVH_CSR_ELL_OVERFLOW) ? 1 : 0;
   if (out_bits) out_mask = reinterpret_cast<const float*>(out_bits);
   d.B = B; d.N = N; d.K = K; d.CP = CP; d.CQtot = CQ; d.pairs = lap->ell_pairs;
   d.db_mode = db ? (p_is_x ? 1 : 2) : 0;

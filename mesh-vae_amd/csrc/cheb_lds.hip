@@ -41,6 +41,8 @@ struct LdsConvArgs {
   const int32_t* in_map;    // optional: row v of the input is in[in_map[v]] (zero when < 0)
   const int32_t* pool_inv;  // optional fused one-hot pooling: out row v also goes to pooled[pool_inv[v]]
   float* pooled;
+  const int* col;           // CSR columns: rows longer than the 8 ELL slots continue there (ovf)
+  int ovf;
   const int* pt_rowptr;     // optional (backward): the output rows are pooled by this CSR (n_rows = pt_rows) inside
   const int* pt_col;        // the kernel and ONLY the pooled rows [B][pt_rows][CO] are stored to `out`
   const float* pt_val;
@@ -56,7 +58,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
-  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows;
+  int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows, ovf;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -71,7 +73,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
            const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_in_map,
            const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, uint8_t* __restrict__ p_bits_out,
            const int* __restrict__ p_pt_rowptr, const int* __restrict__ p_pt_col, const float* __restrict__ p_pt_val,
-           LdsConvDims a) {
+           const int* __restrict__ p_col, LdsConvDims a) {
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;  // vertex slots (> N)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -99,6 +101,11 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   float ka2[VPT];
   float xs[VPT][CQ];
   float4 R[VPT];
+  // MVH_CSR_ELL_OVERFLOW (small levels only, TCT == 0): columns 8..11 of the few long rows, two per
+  // word like the ELL (pad = zero row N), fetched once; ovf_any[vi] keeps the extra gathers branchy
+  constexpr bool kOvf = (TCT == 0);
+  uint32_t ovf0[kOvf ? VPT : 1], ovf1[kOvf ? VPT : 1];
+  bool ovf_any[kOvf ? VPT : 1];
   const float* inb = p_in + (long long)mesh * a.in_bs * CQ;
   const bool use_bits = BWD && p_mask && a.mask_bits && (CQ % 4 == 0);
   const float* mkb = (BWD && p_mask && !use_bits) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
@@ -109,10 +116,24 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     const int v = tid + vi * THREADS;
     const bool valid = v < N;
     const int vl = min(v, N - 1);
-    const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
+    const uint32_t rinfo = p_rowinfo[vl];
+    const float deg = valid ? (float)(rinfo & 255u) : 0.f;
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (kOvf) {
+      const unsigned padw = (unsigned)N | ((unsigned)N << 16);
+      ovf0[vi] = ovf1[vi] = padw;
+      const int dg = valid ? (int)(rinfo & 255u) : 0;
+      ovf_any[vi] = a.ovf && dg > 8;
+      if (ovf_any[vi]) {
+        const int* cp = p_col + (rinfo >> 8) + 8;
+        const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
+        const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
+        ovf0[vi] = c0 | (c1 << 16);
+        ovf1[vi] = c2 | (c3 << 16);
+      }
+    }
     int rl = vl;  // input row (through the optional selection map: un-pooled gradient rows)
     if (p_in_map) {
       const int rr = p_in_map[vl];
@@ -214,6 +235,16 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           add4(g, n3);
         }
         asm volatile("" ::: "memory");
+      }
+      if constexpr (kOvf) {
+        if (ovf_any[vi]) {  // columns 8..11 of a long row, after the ELL slots (same order as a 16-wide list)
+          const float4 n0 = slab[ovf0[vi] & 0xffffu], n1 = slab[ovf0[vi] >> 16];
+          const float4 n2 = slab[ovf1[vi] & 0xffffu], n3 = slab[ovf1[vi] >> 16];
+          add4(g, n0);
+          add4(g, n1);
+          add4(g, n2);
+          add4(g, n3);
+        }
       }
       const float kk = ka2[vi] * scale;
       acc[vi].x = fmaf(kk, g.x, acc[vi].x);
@@ -409,9 +440,9 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
-                a.mask_bits, a.pt_rows};
+                a.mask_bits, a.pt_rows, a.ovf};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
-                     a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, d);
+                     a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, a.col, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -455,7 +486,7 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   int vpt, threads;
   if (N + 1 <= 1024) { vpt = 1; threads = ((N + 1 + 63) / 64) * 64; }
   else if (N + 1 <= 2048) { vpt = 2; threads = (((N + 2) / 2 + 63) / 64) * 64; }
-  else if (N + 1 <= 5120 && CQ <= 16) {
+  else if (N + 1 <= 5120 && CQ <= 16 && !(lap->flags & MVH_CSR_ELL_OVERFLOW)) {
     // 1024 threads x 5 vertices (4 waves/SIMD, 128 VGPRs) measured 5 % faster than 512 x 10
     // (2 waves/SIMD, 256 VGPRs); MESHVAE_L0_CFG=10 selects the latter for A/B runs
     static const char* cfg = getenv("MESHVAE_L0_CFG");
@@ -480,6 +511,7 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   }
   a.in = in; a.mask = mask; a.W = prepacked ? prepacked : wpack; a.bias = bias; a.out = out;
   a.rowinfo = lap->rowinfo; a.ell = lap->ell;
+  a.col = lap->col; a.ovf = (lap->flags & MVH_CSR_ELL_OVERFLOW) ? 1 : 0;
   a.B = B; a.N = N; a.K = K; a.CO = CO; a.Cin = Cin; a.Cout = Cout;
   a.pairs = lap->ell_pairs; a.act = act;
   a.in_bs = o.in_bs > 0 ? o.in_bs : N;

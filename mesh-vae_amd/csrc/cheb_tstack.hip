@@ -227,7 +227,7 @@ size_t tstack_ws_floats(int B, int N, int K, int Cin, int Cout) {
 bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K) {
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap || !pool || !lap->rowinfo || !lap->ell || (lap->flags & need) != need) return false;
-  if (lap->ell_pairs <= 0 || lap->ell_pairs > 8) return false;
+  if (lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & MVH_CSR_ELL_OVERFLOW)) return false;
   if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0) return false;
   if (Cin < 1 || Cin > 4 || Cout < 4 || Cout > 32 || Cout % 4 != 0 || K < 1 || K > 8) return false;
   if (K * Cin * Cout + Cout > 512) return false;

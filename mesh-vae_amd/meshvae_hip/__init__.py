@@ -40,7 +40,7 @@ class VaeDesc(ctypes.Structure):
                 ("up", CsrStruct * VAE_MAX_LAYERS), ("up_t", CsrStruct * VAE_MAX_LAYERS)]
 
 
-CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION = 1, 2, 4
+CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 

@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from . import CSR_NORMALIZED_LAPLACIAN, CSR_SELECTION, CSR_SYMMETRIC, CsrStruct
+from . import CSR_ELL_OVERFLOW, CSR_NORMALIZED_LAPLACIAN, CSR_SELECTION, CSR_SYMMETRIC, CsrStruct
 
 
 class Csr:
@@ -55,10 +55,17 @@ class Csr:
             info = ((rowptr[:-1] << 8) | counts).numpy().astype("uint32")      # bit pattern kept in int32
             self.rowinfo = torch.from_numpy(info.view("int32")).to(device)
             self.ell_pairs = (self.max_row_nnz + 1) // 2
+            pos = torch.arange(self.nnz) - rowptr[:-1][out_idx[order]]          # position inside the row
+            keep = torch.ones(self.nnz, dtype=torch.bool)
+            if 8 < self.max_row_nnz <= 12:
+                # a few long rows (2-6 % of a decimated level) would double the padded width for every
+                # vertex: the list keeps the first 8 columns, the kernels fetch the rest from `col`
+                self.flags |= CSR_ELL_OVERFLOW
+                self.ell_pairs = 4
+                keep = pos < 8
             pw = 4 if self.ell_pairs <= 4 else 8 * ((self.ell_pairs + 7) // 8)   # words per vertex (16-byte groups)
             slots = torch.full((self.n_rows, 2 * pw), self.n_cols, dtype=torch.int64)
-            pos = torch.arange(self.nnz) - rowptr[:-1][out_idx[order]]          # position inside the row
-            slots[out_idx[order], pos] = col_sorted
+            slots[out_idx[order][keep], pos[keep]] = col_sorted[keep]
             packed = (slots[:, 0::2] | (slots[:, 1::2] << 16)).contiguous()     # [n_rows, pw] vertex-major
             self.ell = torch.from_numpy(packed.numpy().astype("uint32").view("int32")).to(device)
         self.struct = CsrStruct(self.n_rows, self.n_cols, self.nnz, self.rowptr.data_ptr(),
