@@ -188,40 +188,23 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
     }
     __syncthreads();
   }
-  if (t < n_out) partial[(long long)blockIdx.x * n_out + t] = acc;
-}
-
-__global__ void __launch_bounds__(1024)
-k_stack_dw_finish(const float* __restrict__ partial, int nblocks, int n_w, int n_out, float* __restrict__ dW,
-                  float* __restrict__ db) {
-  // group g of 1024 / n_out sums blocks g, g + G, ... with 4 independent chains; groups combined in order
-  __shared__ float red[1024];
-  const int G = 1024 / n_out;
-  const int g = threadIdx.x / n_out, e = threadIdx.x - g * n_out;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (g < G) {
-    int b = g;
-    for (; b + 3 * G < nblocks; b += 4 * G) {
-      s0 += partial[(long long)b * n_out + e];
-      s1 += partial[(long long)(b + G) * n_out + e];
-      s2 += partial[(long long)(b + 2 * G) * n_out + e];
-      s3 += partial[(long long)(b + 3 * G) * n_out + e];
-    }
-    for (; b < nblocks; b += G) s0 += partial[(long long)b * n_out + e];
+  // partial tile in the layout of the LDS dW kernel (slab 0, [k][q = co][j = ci], plane K = db), so the
+  // step engine's one reduction launch (k_dw_reduce_all) finishes this layer with all the others
+  const int tile = (a.K + 1) * a.Cout * 4;
+  float* pt = partial + (long long)blockIdx.x * tile;
+  if (t < n_w) {
+    const int k = t / (a.Cout * a.Cin), ci = (t / a.Cout) % a.Cin;
+    pt[(k * a.Cout + co) * 4 + ci] = acc;
+  } else if (t < n_out) {
+    pt[(a.K * a.Cout + co) * 4] = acc;
   }
-  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if ((int)threadIdx.x >= n_out) return;
-  float s = 0.f;
-  for (int k = 0; k < G; ++k) s += red[k * n_out + threadIdx.x];
-  if ((int)threadIdx.x < n_w) dW[threadIdx.x] = s;  // [k][ci][co] is the thread order
-  else if (db) db[threadIdx.x - n_w] = s;
 }
 
 // workspace: the stack [B][N+1][K][4], then the per-block partials of the reduction
 size_t tstack_stack_floats(int B, int N, int K) { return (size_t)B * (N + 1) * K * 4; }
 size_t tstack_ws_floats(int B, int N, int K, int Cin, int Cout) {
-  return tstack_stack_floats(B, N, K) + (size_t)kSdwGrid * ((size_t)K * Cin * Cout + Cout) + 64;
+  (void)Cin;
+  return tstack_stack_floats(B, N, K) + (size_t)kSdwGrid * ((size_t)(K + 1) * Cout * 4) + 64;
 }
 
 bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K) {
@@ -255,16 +238,23 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
 
 // dW [K][Cin][Cout], db [Cout] from the stack and the gradient of the POOLED output dout [B][n_sel][Cout]
 int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,
-                    const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K) {
+                    const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K,
+                    DwReduceEntry* defer) {
   SdwDims d{B * pool->n_rows, pool->n_rows, N, K, Cin, Cout};
-  const int n_w = K * Cin * Cout, n_out = n_w + Cout;
   int grid = (d.rows + kSdwRows - 1) / kSdwRows;
   if (grid > kSdwGrid) grid = kSdwGrid;
   hipLaunchKernelGGL(k_stack_dw, dim3(grid), dim3(512), 0, st, stack, dout, bits, out_mask, pool->col, partial, d);
   MVH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_stack_dw_finish, dim3(1), dim3(1024), 0, st, partial, grid, n_w, n_out, dW, db);
-  MVH_LAUNCH_CHECK();
-  return MVH_OK;
+  // the partial tiles are summed by the dW reduction kernel (fixed order over the blocks)
+  const DwReduceEntry ent{partial, grid, 1, K, Cout, Cin, 1, Cin, Cout, db ? 1 : 0, dW, db};
+  if (defer) {
+    *defer = ent;
+    return MVH_OK;
+  }
+  DwReduceTable t;
+  t.n = 1;
+  t.e[0] = ent;
+  return launch_dw_reduce_all(st, t);
 }
 
 }  // namespace mvh

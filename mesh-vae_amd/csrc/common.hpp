@@ -126,7 +126,8 @@ bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin
 int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
                   int N, int Cin, int K);
 int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,
-                    const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K);
+                    const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K,
+                    DwReduceEntry* defer = nullptr /* leave the final sum to launch_dw_reduce_all */);
 // mvh_vae_loss_fwd with optional gradient seeds for d_loss = 1 (d_recon [B*NV], d_mu/d_logvar [B*Z], d_yhat [B*C])
 int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
                   const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss, void* rec,

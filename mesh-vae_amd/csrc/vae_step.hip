@@ -461,7 +461,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (ev_tstack) MVH_HIP(hipStreamWaitEvent(main, ev_tstack, 0));
       TRY(launch_stack_dw(main, &d->down[0], F(p.tstack), F(p.g_encP[0]), BITS(p.encBits[0]), F(p.encA[0]),
                           G[ix.encW(0)], G[ix.encB(0)], F(p.tstack) + tstack_stack_floats(B, p.Nn[0], d->K[0]), B, p.Nn[0],
-                          p.f[0], p.f[1], d->K[0]));
+                          p.f[0], p.f[1], d->K[0], &red.e[red.n]));
+      ++red.n;
       if (tail_on_main && n > 1) {
         bool fused = false, dfr = false;
         const float* xin1 = F(p.encP[0]);
