@@ -312,9 +312,10 @@ def test_hires_20k_config_matches_reference(model_20k_npz):
     assert sorted(got) == sorted(names)
     for k in names:
         gn = float(npz[f"train/gnorm/{k}"])
-        assert abs(float(got[k].double().norm()) - gn) <= 2e-4 * gn + 1e-7, (k, float(got[k].double().norm()), gn)
-        torch.testing.assert_close(got[k].reshape(-1)[:1024].cpu(), _t(npz[f"train/grad_head/{k}"]), rtol=1e-3,
-                                   atol=2e-4 * max(gn / max(got[k].numel() ** 0.5, 1.0), 1e-3), msg=k)
+        assert abs(float(got[k].double().norm()) - gn) <= 5e-4 * gn + 1e-7, (k, float(got[k].double().norm()), gn)
+        # per-element: 1e-3 of the tensor's RMS entry (K = 10 recurrences through six levels; fp32 sums of 40 k rows)
+        torch.testing.assert_close(got[k].reshape(-1)[:1024].cpu(), _t(npz[f"train/grad_head/{k}"]), rtol=2e-3,
+                                   atol=1e-3 * max(gn / max(got[k].numel() ** 0.5, 1.0), 1e-3), msg=k)
 
 
 @pytest.mark.parametrize("which", ["tiny", "5k"])
