@@ -204,6 +204,16 @@ int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* e
                   float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float grad_scale, int32_t* step_count);
 
+/* ---- around the step: what main.py:88-93 / :139-145 do on the HOST with numpy after
+ * every batch -- de-normalise the reconstruction (out * std + mean, per vertex), undo the Procrustes
+ * alignment of data.py:144 (bmm(mesh * s, R) + m) and take the per-vertex Euclidean distance to the
+ * original mesh (inference.py:50-51) -- as one device pass, so the step needs no D2H sync.
+ * recon [B,N,3]; std, mean [N,3]; R [B,3,3] row-major; m [B,3]; s [B]; gt [B,N,3] or NULL;
+ * mesh_out [B,N,3] or NULL; dist_out [B,N] or NULL (needs gt). */
+int mvh_recon_postprocess(mvh_stream_t stream, const float* recon, const float* std, const float* mean,
+                          const float* R, const float* m, const float* s, const float* gt, float* mesh_out,
+                          float* dist_out, int32_t B, int32_t N);
+
 /* ---- row F: cheb_VAE.forward (cheb_VAE.py:190-251) and loss.backward() (main.py:80) as one
  * native launch sequence.  `desc` describes the model the reference builds in
  * cheb_VAE.__init__ (cheb_VAE.py:106-172): filters = [num_features] + num_conv_filters,

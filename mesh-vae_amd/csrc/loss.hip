@@ -138,9 +138,63 @@ k_loss_bwd_small(const float* __restrict__ mu, const float* __restrict__ logvar,
   }
 }
 
+// main.py:88-93: mesh = bmm((recon * std + mean) * s, R) + m ; dist = ||mesh - gt||_2 per vertex
+__global__ void __launch_bounds__(256)
+k_recon_post(const float* __restrict__ recon, const float* __restrict__ std, const float* __restrict__ mean,
+             const float* __restrict__ R, const float* __restrict__ m, const float* __restrict__ s,
+             const float* __restrict__ gt, float* __restrict__ mesh_out, float* __restrict__ dist_out, long long rows,
+             int N) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const long long b = r / N;
+  const int v = (int)(r - b * N);
+  const float sc = s[b];
+  float p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)  // mul, add, mul with separate roundings, as the three torch ops
+    p[i] = __fmul_rn(__fadd_rn(__fmul_rn(recon[r * 3 + i], std[v * 3 + i]), mean[v * 3 + i]), sc);
+  const float* Rb = R + b * 9;
+  float q[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float a = __fmul_rn(p[0], Rb[j]);
+    a = __fadd_rn(a, __fmul_rn(p[1], Rb[3 + j]));
+    a = __fadd_rn(a, __fmul_rn(p[2], Rb[6 + j]));
+    q[j] = a + m[b * 3 + j];
+  }
+  if (mesh_out) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mesh_out[r * 3 + j] = q[j];
+  }
+  if (dist_out) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float d = gt[r * 3 + j] - q[j];
+      d2 = __fadd_rn(d2, __fmul_rn(d, d));
+    }
+    dist_out[r] = sqrtf(d2);
+  }
+}
+
 }  // namespace mvh
 
 using namespace mvh;
+
+extern "C" int mvh_recon_postprocess(mvh_stream_t stream, const float* recon, const float* std, const float* mean,
+                                     const float* R, const float* m, const float* s, const float* gt,
+                                     float* mesh_out, float* dist_out, int32_t B, int32_t N) {
+  MVH_REQUIRE(recon && std && mean && R && m && s, "recon_postprocess: null tensor");
+  MVH_REQUIRE(B >= 0 && N > 0, "recon_postprocess: bad sizes B=%d N=%d", B, N);
+  MVH_REQUIRE(!dist_out || gt, "recon_postprocess: dist_out needs gt");
+  MVH_REQUIRE(mesh_out || dist_out, "recon_postprocess: nothing to compute");
+  const long long rows = (long long)B * N;
+  if (rows == 0) return MVH_OK;
+  hipLaunchKernelGGL(k_recon_post, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, recon, std, mean, R, m, s,
+                     gt, mesh_out, dist_out, rows, N);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
 
 extern "C" size_t mvh_vae_loss_ws_bytes(int32_t B) { return (size_t)B * kLossSplit * sizeof(double) + 256; }
 

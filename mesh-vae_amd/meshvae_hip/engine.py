@@ -85,6 +85,17 @@ class FusedAdam:
                                       self.weight_decay, float(grad_scale), self.step_count.data_ptr()))
 
 
+def scheduled_lr(config, epoch, current_lr):
+    """The step-wise learning-rate table of the reference's epoch loop (main.py:266-269): every pair
+    (learning_rates_epochs[i], learning_rates[i]) with `epoch > learning_rates_epochs[i]` overwrites the
+    rate, in list order (so the last matching pair wins); no match leaves `current_lr` unchanged."""
+    lr = current_lr
+    for i, e in enumerate(config.get("learning_rates_epochs", [])):
+        if epoch > e:
+            lr = config["learning_rates"][i]
+    return lr
+
+
 class _Batch:
     def __init__(self, x):
         self.x, self.num_graphs, self.edge_index = x.reshape(-1, x.shape[-1]), x.shape[0], None
@@ -234,6 +245,18 @@ class TrainStep:
         torch.normal(mean=0, std=1, size=(self.B, self.net.z), out=buf)
         self.eps.copy_(buf, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
+
+    def set_epoch(self, config, epoch):
+        """Apply the reference's LR table for `epoch` (main.py:266-269).  The rate is a kernel argument of the
+        fused Adam launch, so it takes effect on the next eager step; a captured optimizer graph is re-captured."""
+        lr = scheduled_lr(config, epoch, self.opt.lr)
+        if lr != self.opt.lr:
+            self.opt.lr = lr
+            if self.use_graph and self.graph_opt is not None:
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt):
+                    self.opt.step(1.0 / (self.world * self.n_micro))
+        return lr
 
     def step(self):
         self._draw_eps()

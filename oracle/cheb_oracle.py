@@ -246,6 +246,18 @@ class OracleVAE:
         return {k: v.grad for k, v in self.p.items() if v.grad is not None}
 
 
+def recon_postprocess(out, std, mean, R, m, s, gt_mesh):
+    """main.py:88-93 (train) / :139-145 (evaluate), verbatim dataflow on CPU tensors:
+    de-normalise, undo the Procrustes alignment, per-vertex Euclidean distance (inference.py:50-51).
+    The reference has these lines inline (no importable function, no fixture): parity for this row is
+    pinned only by this restatement of the three expressions."""
+    recon_mesh = out * std + mean
+    s = s.reshape(-1, 1, 1)
+    recon_mesh = torch.bmm(recon_mesh * s, R) + m.reshape(-1, 1, 3)
+    dist = ((gt_mesh - recon_mesh) ** 2).sum(-1).sqrt()
+    return recon_mesh, dist
+
+
 def log_sigma_const():
     """-6 + softplus(1 + 6) (cheb_VAE.py:329-330)."""
     return -6.0 + math.log1p(math.exp(7.0))

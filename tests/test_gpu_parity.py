@@ -433,3 +433,24 @@ def test_edge_cases():
         conv(x, ei2.float(), nrm)
     with pytest.raises(TypeError):
         conv(x.double(), ei2, nrm)
+
+
+def test_recon_postprocess_matches_oracle():
+    """SURVEY 8(f) next #2 (main.py:88-93): de-normalise + inverse Procrustes + per-vertex error on the device."""
+    import postprocess
+    from oracle import cheb_oracle as O
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, N = 5, 4998
+    out, gt = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 3, generator=g)
+    std, mean = torch.rand(N, 3, generator=g) + 0.5, torch.randn(N, 3, generator=g)
+    R = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0].contiguous()
+    m, s = torch.randn(B, 1, 3, generator=g), torch.rand(B, 1, generator=g) + 0.5     # shapes of data.py:111
+    want_mesh, want_dist = O.recon_postprocess(out, std, mean, R, m, s, gt)
+    mesh, dist = postprocess.reconstruction_error(out.to(dev), std, mean, R, m, s, gt)
+    torch.testing.assert_close(mesh.cpu(), want_mesh, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dist.cpu(), want_dist, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(postprocess.reconstruct(out.to(dev), std, mean, R, m, s).cpu(), want_mesh, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(postprocess.euclidean_distances(gt, want_mesh), want_dist, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        postprocess.reconstruct(out, std, mean, R, m, s)

@@ -150,3 +150,34 @@ def test_get_model_side_effects(tmp_path, capsys):
     assert t._indices().tolist() == [[2, 0, 1], [1, 1, 0]] and t._values().tolist() == [1.0, 2.0, 3.0]
     with pytest.raises(NotImplementedError):
         get_model(dict(cfg, topology=None), "cpu")
+
+
+def test_recon_postprocess_oracle_matches_numpy():
+    """SURVEY 8(f) next #2: the oracle's restatement of main.py:88-93 against an independent numpy evaluation."""
+    import torch
+    from oracle import cheb_oracle as O
+    g = np.random.default_rng(5)
+    B, N = 3, 17
+    out, gt = g.standard_normal((B, N, 3)).astype(np.float32), g.standard_normal((B, N, 3)).astype(np.float32)
+    std, mean = (g.random((N, 3)) + 0.5).astype(np.float32), g.standard_normal((N, 3)).astype(np.float32)
+    R = np.linalg.qr(g.standard_normal((B, 3, 3)))[0].astype(np.float32)
+    m, s = g.standard_normal((B, 1, 3)).astype(np.float32), (g.random((B, 1)) + 0.5).astype(np.float32)
+    mesh, dist = O.recon_postprocess(*(torch.from_numpy(a) for a in (out, std, mean, R, m, s, gt)))
+    want = np.einsum("bni,bij->bnj", (out * std + mean) * s[:, None, :], R) + m
+    np.testing.assert_allclose(mesh.numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dist.numpy(), np.sqrt(((gt - want) ** 2).sum(-1)), rtol=1e-5, atol=1e-6)
+
+
+def test_scheduled_lr_follows_reference_table():
+    """main.py:266-269: `if epoch > e: lr = learning_rates[i]` for every i in order."""
+    from meshvae_hip.engine import scheduled_lr
+    cfg = {"learning_rates_epochs": [10, 20, 30], "learning_rates": [1e-3, 5e-4, 1e-4]}
+
+    def ref(epoch, lr):
+        for i, e in enumerate(cfg["learning_rates_epochs"]):
+            if epoch > e:
+                lr = cfg["learning_rates"][i]
+        return lr
+    for epoch in (1, 10, 11, 20, 21, 30, 31, 300):
+        assert scheduled_lr(cfg, epoch, 8e-3) == ref(epoch, 8e-3)
+    assert scheduled_lr({}, 5, 3e-3) == 3e-3
