@@ -78,7 +78,13 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   const int VS = VPT * THREADS;  // vertex slots (> N)
   extern __shared__ __align__(16) unsigned char smem[];
   float4* slab = reinterpret_cast<float4*>(smem);             // [VS]; rows >= N stay zero
-  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);           // [VS][PW/4]
+  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);           // [VS][PW/4]  (kDB: the second slab instead)
+  // Small levels (TCT == 0: one or two vertices per thread, registers to spare): the neighbour ids of the
+  // thread's own vertices live in VGPRs (nobody else needs them) and the LDS holds TWO slabs, u_{k+1}
+  // and u_{k+2}: an order gathers from one, reads/overwrites only its OWN rows of the other, so it needs
+  // ONE barrier instead of two, no register copy of u_{k+2}, no ELL image and no staging pass.
+  constexpr bool kDB = (TCT == 0);
+  float4* slabB = slab + VS;
 
   // blocks b and b+8 share an XCD: keep the slabs of one mesh on one L2 (speed only)
   const int NS = (a.CO + 3) >> 2;
@@ -87,7 +93,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   if (mesh >= a.B) return;  // uniform per block, before any barrier
   const int tid = threadIdx.x, N = a.N;
 
-  {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
+  if constexpr (!kDB) {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
     const uint4 pad4 = make_uint4(pad, pad, pad, pad);
     const uint4* src = reinterpret_cast<const uint4*>(p_ell);
@@ -96,6 +102,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       ellv[i] = (v < N) ? src[i] : pad4;
     }
   }
+  uint4 ids[kDB ? VPT : 1][PW / 4];
 
   // ---- own vertices: -2/deg and the input rows scaled by s = deg^-1/2 (0 for slots past N)
   float ka2[VPT];
@@ -121,6 +128,12 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (kDB) {
+      const unsigned padi = (unsigned)N | ((unsigned)N << 16);
+#pragma unroll
+      for (int q = 0; q < PW / 4; ++q)
+        ids[vi][q] = valid ? reinterpret_cast<const uint4*>(p_ell)[vl * (PW / 4) + q] : make_uint4(padi, padi, padi, padi);
+    }
     if constexpr (kOvf) {
       const unsigned padw = (unsigned)N | ((unsigned)N << 16);
       ovf0[vi] = ovf1[vi] = padw;
@@ -209,14 +222,16 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     }
   };
   // acc[vi] += (scale * -2/deg) * sum_{j in N(v)} slab[j]
-  auto gather_axpy = [&](float4(&acc)[VPT], float scale) {
+  auto gather_axpy = [&](float4(&acc)[VPT], float scale, const float4* slab) {  // (shadows the kernel's `slab`)
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       const int v = tid + vi * THREADS;
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < PW / 4; ++q) {
-        const uint4 id = ellv[v * (PW / 4) + q];
+        uint4 id;
+        if constexpr (kDB) id = ids[vi][q];
+        else id = ellv[v * (PW / 4) + q];
         {
           const float4 n0 = slab[id.x & 0xffffu], n1 = slab[id.x >> 16];
           const float4 n2 = slab[id.y & 0xffffu], n3 = slab[id.y >> 16];
@@ -254,46 +269,76 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     }
   };
 
+  float4* stage = slab;  // where a fused pooling parks the result rows
   if (a.K >= 2) {
     contract(R, a.K - 1);
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       slab[tid + vi * THREADS] = R[vi];         // u_{K-1} (zero in the slots past N)
+      if constexpr (kDB) slabB[tid + vi * THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);  // u_K = 0
       R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);  // u_K = 0
     }
-    __syncthreads();  // slab + ELL staged
+    __syncthreads();  // slab (+ ELL image) staged
     // Waves w and w + NW/2 share a SIMD: the second half gathers first and contracts after, so at any
     // time one partner is on the VALU (weight FMAs) while the other waits on LDS gathers
     // (MI355X_MICROARCH "two waves per SIMD": split roles by wave number >= NW/2, not by parity).
     const bool gather_first = (tid >> 6) >= (THREADS >> 7) && THREADS >= 128;
-    for (int k = a.K - 2; k >= 1; --k) {
+    if constexpr (kDB) {
+      float4* cur = slab;   // u_{k+1}, gathered by everyone
+      float4* oth = slabB;  // u_{k+2}, touched only through the thread's own rows
+      for (int k = a.K - 2; k >= 0; --k) {
+#pragma unroll
+        for (int vi = 0; vi < VPT; ++vi) {
+          const float4 o = oth[tid + vi * THREADS];
+          R[vi] = make_float4(-o.x, -o.y, -o.z, -o.w);
+        }
+        const float sc = (k == 0) ? 0.5f : 1.0f;
+        if (gather_first) {
+          gather_axpy(R, sc, cur);
+          contract(R, k);
+        } else {
+          contract(R, k);
+          gather_axpy(R, sc, cur);
+        }
+        if (k == 0) break;  // R is the result; `oth` is free for the epilogue
+#pragma unroll
+        for (int vi = 0; vi < VPT; ++vi) oth[tid + vi * THREADS] = R[vi];  // own rows only: no barrier before
+        __syncthreads();
+        float4* t = cur;
+        cur = oth;
+        oth = t;
+      }
+      stage = oth;
+    } else {
+      for (int k = a.K - 2; k >= 1; --k) {
+#pragma unroll
+        for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
+        if (gather_first) {
+          gather_axpy(R, 1.0f, slab);
+          contract(R, k);
+        } else {
+          contract(R, k);
+          gather_axpy(R, 1.0f, slab);
+        }
+        __syncthreads();  // every gather of u_{k+1} is done
+#pragma unroll
+        for (int vi = 0; vi < VPT; ++vi) {
+          const int v = tid + vi * THREADS;
+          const float4 old = slab[v];
+          slab[v] = R[vi];
+          R[vi] = old;
+        }
+        __syncthreads();
+      }
 #pragma unroll
       for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
       if (gather_first) {
-        gather_axpy(R, 1.0f);
-        contract(R, k);
+        gather_axpy(R, 0.5f, slab);
+        contract(R, 0);
       } else {
-        contract(R, k);
-        gather_axpy(R, 1.0f);
+        contract(R, 0);
+        gather_axpy(R, 0.5f, slab);
       }
-      __syncthreads();  // every gather of u_{k+1} is done
-#pragma unroll
-      for (int vi = 0; vi < VPT; ++vi) {
-        const int v = tid + vi * THREADS;
-        const float4 old = slab[v];
-        slab[v] = R[vi];
-        R[vi] = old;
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
-    if (gather_first) {
-      gather_axpy(R, 0.5f);
-      contract(R, 0);
-    } else {
-      contract(R, 0);
-      gather_axpy(R, 0.5f);
     }
   } else {
     contract(R, 0);
@@ -313,13 +358,14 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   // operator's CSR order (the arithmetic of k_spmm<.., EXACT>).  Backward: ONLY the pooled rows are
   // stored (to `out`; no [B, N, C] gradient tensor); forward: `out` as usual + pooled rows to `pooled`.
   const bool scatter = p_pt_rowptr != nullptr;
-  if (scatter) __syncthreads();  // the last gathers of u_1 are done: the slab is free
+  // (single slab: wait for the last gathers of u_1; two slabs: the rows go to the one nobody gathers from)
+  if (scatter && !(kDB && a.K >= 2)) __syncthreads();
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
     const int v = tid + vi * THREADS;
     if (BWD && scatter && v < N) {
       const float inv_s = ka2[vi] < 0.f ? __builtin_amdgcn_rsqf(-0.5f * ka2[vi]) : 1.0f;
-      slab[v] = make_float4(R[vi].x * inv_s, R[vi].y * inv_s, R[vi].z * inv_s, R[vi].w * inv_s);
+      stage[v] = make_float4(R[vi].x * inv_s, R[vi].y * inv_s, R[vi].z * inv_s, R[vi].w * inv_s);
       continue;
     }
     if (v >= N) continue;
@@ -334,7 +380,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     if (!BWD && p_bits_out)  // CO % 4 == 0 (checked on the host): one sign byte per (vertex, slab)
       p_bits_out[((long long)mesh * a.out_bs + v) * (a.CO >> 2) + (s0 >> 2)] =
           (uint8_t)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
-    if (!BWD && scatter) slab[v] = make_float4(o[0], o[1], o[2], o[3]);
+    if (!BWD && scatter) stage[v] = make_float4(o[0], o[1], o[2], o[3]);
     float* dst = outb + (long long)v * a.CO + s0;
     const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
@@ -357,7 +403,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       const int e1 = p_pt_rowptr[c + 1];
       for (int e = p_pt_rowptr[c]; e < e1; ++e) {
         const float w = p_pt_val[e];
-        const float4 n = slab[p_pt_col[e]];
+        const float4 n = stage[p_pt_col[e]];
         acc.x = __fadd_rn(acc.x, __fmul_rn(w, n.x));
         acc.y = __fadd_rn(acc.y, __fmul_rn(w, n.y));
         acc.z = __fadd_rn(acc.z, __fmul_rn(w, n.z));
@@ -430,7 +476,7 @@ static bool force_generic() {  // read per call: the tests flip it inside one pr
 template <int CQ, int VPT, int TCT, int PW, bool BWD>
 static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   auto kern = k_cheb_lds<CQ, VPT, TCT, PW, BWD>;
-  const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
+  const size_t lds = (size_t)VPT * threads * (TCT == 0 ? 32 : 16 + PW * 4);
   static size_t attr_bytes = 0;
   if (lds > attr_bytes) {
     MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
