@@ -110,6 +110,36 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const float* Qm = (p_Qmask && !a.mask_bits) ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
   const uint8_t* Qbits = (p_Qmask && a.mask_bits)
                              ? reinterpret_cast<const uint8_t*>(p_Qmask) + (long long)mesh * a.bs * (CQT / 4) : nullptr;
+  // Fast path of the train step's decoder layers (sign bytes, no row map, full channel groups): the loop
+  // body is branch-free, so the scheduler can keep the loads of many steps in flight; the general loop
+  // below has wave-uniform branches per step, which serialise its 40 global loads at the 5k level.
+  const bool fast_q = !SPLIT && Qbits != nullptr && a.map_side != 2 && (CQ % 16 == 0);
+  if (fast_q) {
+#pragma unroll
+    for (int s = 0; s < STEPS_CT; ++s) {
+      const int v = 16 * (s * NW + wave) + (lane >> 2);
+      const int vl = min(v, N - 1);
+      const float deg = (float)(p_rowinfo[vl] & 255u);
+      float inv_s = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
+      inv_s = (v < N) ? inv_s : 0.f;
+      const float live = (v < N) ? 1.f : 0.f;
+#pragma unroll
+      for (int h = 0; h < QH; ++h) {
+        const int c0 = 16 * h + 4 * (lane & 3);
+        float4 t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
+        const uint32_t m = Qbits[vl * (CQ / 4) + (c0 >> 2)];
+        t.x = (m & 1u) ? t.x : 0.f;
+        t.y = (m & 2u) ? t.y : 0.f;
+        t.z = (m & 4u) ? t.z : 0.f;
+        t.w = (m & 8u) ? t.w : 0.f;
+        qsum[h].x = fmaf(live, t.x, qsum[h].x);
+        qsum[h].y = fmaf(live, t.y, qsum[h].y);
+        qsum[h].z = fmaf(live, t.z, qsum[h].z);
+        qsum[h].w = fmaf(live, t.w, qsum[h].w);
+        qreg[SPLIT ? 0 : s][h] = make_float4(t.x * inv_s, t.y * inv_s, t.z * inv_s, t.w * inv_s);
+      }
+    }
+  } else
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
     const int v = 16 * (s * NW + wave) + (lane >> 2);
