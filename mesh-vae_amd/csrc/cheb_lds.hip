@@ -23,6 +23,8 @@
 // HBM traffic is the module boundary: read In once (per slab, L2-shared), write out once.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace mvh {
 
 struct LdsConvArgs {
@@ -118,88 +120,114 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   const float* mkb = (BWD && p_mask && !use_bits) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
   // ReLU sign bytes written by the forward kernel: CQ/4 bytes per vertex, bit j of byte c/4 = out[v][c+j] > 0
   const uint8_t* mbits = reinterpret_cast<const uint8_t*>(p_mask) + (long long)mesh * a.mask_bs * (CQ / 4);
-#pragma unroll
-  for (int vi = 0; vi < VPT; ++vi) {
-    const int v = tid + vi * THREADS;
-    const bool valid = v < N;
-    const int vl = min(v, N - 1);
-    const uint32_t rinfo = p_rowinfo[vl];
-    const float deg = valid ? (float)(rinfo & 255u) : 0.f;
-    ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
-    float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-    R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (kDB) {
-      const unsigned padi = (unsigned)N | ((unsigned)N << 16);
-#pragma unroll
-      for (int q = 0; q < PW / 4; ++q)
-        ids[vi][q] = valid ? reinterpret_cast<const uint4*>(p_ell)[vl * (PW / 4) + q] : make_uint4(padi, padi, padi, padi);
-    }
-    if constexpr (kOvf) {
-      const unsigned padw = (unsigned)N | ((unsigned)N << 16);
-      ovf0[vi] = ovf1[vi] = padw;
-      const int dg = valid ? (int)(rinfo & 255u) : 0;
-      ovf_any[vi] = a.ovf && dg > 8;
-      if (ovf_any[vi]) {
-        const int* cp = p_col + (rinfo >> 8) + 8;
-        const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
-        const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
-        ovf0[vi] = c0 | (c1 << 16);
-        ovf1[vi] = c2 | (c3 << 16);
+  // The row map and the mask mode are wave-uniform; as run-time branches they would fence every vertex's
+  // loads into its own basic block (one memory round trip per vertex).  The loop is therefore a generic
+  // lambda instantiated per (map, mask mode) and dispatched once, so each copy is straight-line code.
+  auto load_rows = [&](auto map_tag, auto mask_tag) {
+    constexpr bool kMap = decltype(map_tag)::value;
+    constexpr int kMask = decltype(mask_tag)::value;  // 0 none, 1 fp32 mask, 2 sign bytes
+  #pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      const bool valid = v < N;
+      const int vl = min(v, N - 1);
+      const uint32_t rinfo = p_rowinfo[vl];
+      const float deg = valid ? (float)(rinfo & 255u) : 0.f;
+      ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+      float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+      R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (kDB) {
+        const unsigned padi = (unsigned)N | ((unsigned)N << 16);
+  #pragma unroll
+        for (int q = 0; q < PW / 4; ++q)
+          ids[vi][q] = valid ? reinterpret_cast<const uint4*>(p_ell)[vl * (PW / 4) + q] : make_uint4(padi, padi, padi, padi);
       }
-    }
-    int rl = vl;  // input row (through the optional selection map: un-pooled gradient rows)
-    if (p_in_map) {
-      const int rr = p_in_map[vl];
-      if (rr < 0) s = 0.f;
-      rl = max(rr, 0);
-    }
-    if constexpr (CQ % 4 == 0) {
-      uint32_t mw[(CQ + 15) / 16];
-#pragma unroll
-      for (int h = 0; h < (CQ + 15) / 16; ++h) mw[h] = 0xffffffffu;
-      if (use_bits) {
-        if constexpr (CQ % 16 == 0) {
-#pragma unroll
-          for (int h = 0; h < CQ / 16; ++h) mw[h] = reinterpret_cast<const uint32_t*>(mbits)[vl * (CQ / 16) + h];
-        } else if constexpr (CQ == 8) {
-          mw[0] = reinterpret_cast<const uint16_t*>(mbits)[vl];
-        } else {
-#pragma unroll
-          for (int c = 0; c < CQ; c += 4) {
-            if (c % 16 == 0) mw[c / 16] = 0;
-            mw[c / 16] |= (uint32_t)mbits[vl * (CQ / 4) + c / 4] << (2 * (c % 16));
+      if constexpr (kOvf) {
+        const unsigned padw = (unsigned)N | ((unsigned)N << 16);
+        ovf0[vi] = ovf1[vi] = padw;
+        const int dg = valid ? (int)(rinfo & 255u) : 0;
+        ovf_any[vi] = a.ovf && dg > 8;
+        if (ovf_any[vi]) {
+          const int* cp = p_col + (rinfo >> 8) + 8;
+          const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
+          const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
+          ovf0[vi] = c0 | (c1 << 16);
+          ovf1[vi] = c2 | (c3 << 16);
+        }
+      }
+      int rl = vl;  // input row (through the optional selection map: un-pooled gradient rows)
+      if constexpr (kMap) {
+        const int rr = p_in_map[vl];
+        if (rr < 0) s = 0.f;
+        rl = max(rr, 0);
+      }
+      if constexpr (CQ % 4 == 0) {
+        uint32_t mw[(CQ + 15) / 16];
+  #pragma unroll
+        for (int h = 0; h < (CQ + 15) / 16; ++h) mw[h] = 0xffffffffu;
+        if constexpr (kMask == 2) {
+          if constexpr (CQ % 16 == 0) {
+  #pragma unroll
+            for (int h = 0; h < CQ / 16; ++h) mw[h] = reinterpret_cast<const uint32_t*>(mbits)[vl * (CQ / 16) + h];
+          } else if constexpr (CQ == 8) {
+            mw[0] = reinterpret_cast<const uint16_t*>(mbits)[vl];
+          } else {
+  #pragma unroll
+            for (int c = 0; c < CQ; c += 4) {
+              if (c % 16 == 0) mw[c / 16] = 0;
+              mw[c / 16] |= (uint32_t)mbits[vl * (CQ / 4) + c / 4] << (2 * (c % 16));
+            }
           }
         }
-      }
-#pragma unroll
-      for (int c = 0; c < CQ; c += 4) {
-        float4 t = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
-        if (use_bits) {
-          const uint32_t m = mw[c / 16] >> (2 * (c % 16));
-          t.x = (m & 1u) ? t.x : 0.f;
-          t.y = (m & 2u) ? t.y : 0.f;
-          t.z = (m & 4u) ? t.z : 0.f;
-          t.w = (m & 8u) ? t.w : 0.f;
+  #pragma unroll
+        for (int c = 0; c < CQ; c += 4) {
+          float4 t = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
+          if constexpr (kMask == 2) {
+            const uint32_t m = mw[c / 16] >> (2 * (c % 16));
+            t.x = (m & 1u) ? t.x : 0.f;
+            t.y = (m & 2u) ? t.y : 0.f;
+            t.z = (m & 4u) ? t.z : 0.f;
+            t.w = (m & 8u) ? t.w : 0.f;
+          }
+          if constexpr (kMask == 1) {
+            const float4 m = *reinterpret_cast<const float4*>(mkb + (long long)vl * CQ + c);
+            t.x = m.x > 0.f ? t.x : 0.f;
+            t.y = m.y > 0.f ? t.y : 0.f;
+            t.z = m.z > 0.f ? t.z : 0.f;
+            t.w = m.w > 0.f ? t.w : 0.f;
+          }
+          xs[vi][c] = t.x * s;
+          xs[vi][c + 1] = t.y * s;
+          xs[vi][c + 2] = t.z * s;
+          xs[vi][c + 3] = t.w * s;
         }
-        if (mkb) {
-          const float4 m = *reinterpret_cast<const float4*>(mkb + (long long)vl * CQ + c);
-          t.x = m.x > 0.f ? t.x : 0.f;
-          t.y = m.y > 0.f ? t.y : 0.f;
-          t.z = m.z > 0.f ? t.z : 0.f;
-          t.w = m.w > 0.f ? t.w : 0.f;
+      } else {
+  #pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+          float t = inb[(long long)rl * CQ + c];
+          if constexpr (kMask == 1) {
+            if (!(mkb[(long long)vl * CQ + c] > 0.f)) t = 0.f;
+          }
+          xs[vi][c] = t * s;
         }
-        xs[vi][c] = t.x * s;
-        xs[vi][c + 1] = t.y * s;
-        xs[vi][c + 2] = t.z * s;
-        xs[vi][c + 3] = t.w * s;
       }
+    }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    const int mm = use_bits ? 2 : (mkb ? 1 : 0);
+    if (p_in_map) {
+      if (mm == 2) load_rows(T{}, M2{});
+      else if (mm == 1) load_rows(T{}, M1{});
+      else load_rows(T{}, M0{});
     } else {
-#pragma unroll
-      for (int c = 0; c < CQ; ++c) {
-        float t = inb[(long long)rl * CQ + c];
-        if (mkb && !(mkb[(long long)vl * CQ + c] > 0.f)) t = 0.f;
-        xs[vi][c] = t * s;
-      }
+      if (mm == 2) load_rows(F{}, M2{});
+      else if (mm == 1) load_rows(F{}, M1{});
+      else load_rows(F{}, M0{});
     }
   }
 
