@@ -20,6 +20,8 @@
 // the partials in fixed order (bitwise reproducible, no atomics) and scatters them into dW / db.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace mvh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -223,69 +225,82 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const uint8_t* Pbits = (p_Pmask && a.mask_bits)
                              ? reinterpret_cast<const uint8_t*>(p_Pmask) + (long long)mesh * a.bs * (a.CP >> 2) : nullptr;
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
-#pragma unroll
-  for (int vi = 0; vi < VPT; ++vi) {
-    const int v = tid + vi * THREADS;
-    const bool valid = v < N;
-    const int vl = min(v, N - 1);
-    const uint32_t rinfo = p_rowinfo[vl];
-    const float deg = valid ? (float)(rinfo & 255u) : 0.f;
-    ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
-    const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-    if constexpr (kOvf) {
-      const unsigned padw = (unsigned)N | ((unsigned)N << 16);
-      ovf0[vi] = ovf1[vi] = padw;
-      const int dg = valid ? (int)(rinfo & 255u) : 0;
-      ovf_any[vi] = a.ovf && dg > 8;
-      if (ovf_any[vi]) {
-        const int* cp = p_col + (rinfo >> 8) + 8;
-        const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
-        const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
-        ovf0[vi] = c0 | (c1 << 16);
-        ovf1[vi] = c2 | (c3 << 16);
-      }
-    }
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    int pl = vl;
-    bool phave = true;
-    if (a.map_side == 1) {
-      const int rr = p_map[vl];
-      phave = rr >= 0;
-      pl = max(rr, 0);
-    }
-    if (slab_full) {
-      float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
-      if (!phave) tv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (Pm) {
-        const float4 m = *reinterpret_cast<const float4*>(Pm + (long long)vl * a.CP + s0);
-        tv.x = m.x > 0.f ? tv.x : 0.f;
-        tv.y = m.y > 0.f ? tv.y : 0.f;
-        tv.z = m.z > 0.f ? tv.z : 0.f;
-        tv.w = m.w > 0.f ? tv.w : 0.f;
-      }
-      if (Pbits) {  // CP % 4 == 0 (host check)
-        const uint32_t m = Pbits[vl * (a.CP >> 2) + sl];
-        tv.x = (m & 1u) ? tv.x : 0.f;
-        tv.y = (m & 2u) ? tv.y : 0.f;
-        tv.z = (m & 4u) ? tv.z : 0.f;
-        tv.w = (m & 8u) ? tv.w : 0.f;
-      }
-      t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (s0 + j < a.CP) {
-          float x = phave ? Pb[(long long)pl * a.CP + s0 + j] : 0.f;
-          if (Pm && !(Pm[(long long)vl * a.CP + s0 + j] > 0.f)) x = 0.f;
-          t[j] = x;
+  // (as in cheb_lds.hip: the wave-uniform mode branches would fence each vertex's loads, so the loop is
+  //  instantiated per mode -- 0 plain full slab, 1 fp32 mask, 2 sign bytes, 3 general (row map, partial slab))
+  auto load_p = [&](auto mode_tag) {
+    constexpr int kMode = decltype(mode_tag)::value;
+  #pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      const bool valid = v < N;
+      const int vl = min(v, N - 1);
+      const uint32_t rinfo = p_rowinfo[vl];
+      const float deg = valid ? (float)(rinfo & 255u) : 0.f;
+      ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+      const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+      if constexpr (kOvf) {
+        const unsigned padw = (unsigned)N | ((unsigned)N << 16);
+        ovf0[vi] = ovf1[vi] = padw;
+        const int dg = valid ? (int)(rinfo & 255u) : 0;
+        ovf_any[vi] = a.ovf && dg > 8;
+        if (ovf_any[vi]) {
+          const int* cp = p_col + (rinfo >> 8) + 8;
+          const unsigned c0 = (unsigned)cp[0], c1 = dg > 9 ? (unsigned)cp[1] : (unsigned)N;
+          const unsigned c2 = dg > 10 ? (unsigned)cp[2] : (unsigned)N, c3 = dg > 11 ? (unsigned)cp[3] : (unsigned)N;
+          ovf0[vi] = c0 | (c1 << 16);
+          ovf1[vi] = c2 | (c3 << 16);
         }
+      }
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      int pl = vl;
+      bool phave = true;
+      if constexpr (kMode == 3) {
+        if (a.map_side == 1) {
+          const int rr = p_map[vl];
+          phave = rr >= 0;
+          pl = max(rr, 0);
+        }
+      }
+      if (kMode != 3 || slab_full) {
+        float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
+        if (!phave) tv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((kMode == 1 || kMode == 3) && Pm) {
+          const float4 m = *reinterpret_cast<const float4*>(Pm + (long long)vl * a.CP + s0);
+          tv.x = m.x > 0.f ? tv.x : 0.f;
+          tv.y = m.y > 0.f ? tv.y : 0.f;
+          tv.z = m.z > 0.f ? tv.z : 0.f;
+          tv.w = m.w > 0.f ? tv.w : 0.f;
+        }
+        if ((kMode == 2 || kMode == 3) && Pbits) {  // CP % 4 == 0 (host check)
+          const uint32_t m = Pbits[vl * (a.CP >> 2) + sl];
+          tv.x = (m & 1u) ? tv.x : 0.f;
+          tv.y = (m & 2u) ? tv.y : 0.f;
+          tv.z = (m & 4u) ? tv.z : 0.f;
+          tv.w = (m & 8u) ? tv.w : 0.f;
+        }
+        t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
+      } else {
+  #pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (s0 + j < a.CP) {
+            float x = phave ? Pb[(long long)pl * a.CP + s0 + j] : 0.f;
+            if (Pm && !(Pm[(long long)vl * a.CP + s0 + j] > 0.f)) x = 0.f;
+            t[j] = x;
+          }
+      }
+      {
+        const float live = valid ? 1.f : 0.f;  // (branch-free)
+        psum.x = fmaf(live, t[0], psum.x); psum.y = fmaf(live, t[1], psum.y);
+        psum.z = fmaf(live, t[2], psum.z); psum.w = fmaf(live, t[3], psum.w);
+      }
+      slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);  // zero in the slots past N
+      R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (valid) {
-      psum.x += t[0]; psum.y += t[1]; psum.z += t[2]; psum.w += t[3];
-    }
-    slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);  // zero in the slots past N
-    R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  };
+  if (a.map_side == 1 || !slab_full) load_p(std::integral_constant<int, 3>{});
+  else if (Pbits) load_p(std::integral_constant<int, 2>{});
+  else if (Pm) load_p(std::integral_constant<int, 1>{});
+  else load_p(std::integral_constant<int, 0>{});
   if (a.db_mode == 2 && q0 == 0) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
     float* pk = part + (long long)a.K * CQT * 4;
     float v4[4] = {psum.x, psum.y, psum.z, psum.w};

@@ -53,8 +53,8 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     inv_s[vi] = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < a.Cin) t[c] = xb[(long long)vl * a.Cin + c];
+    for (int c = 0; c < 4; ++c)  // branch-free (clamped index, selected afterwards): the vertices' loads overlap
+      t[c] = (c < a.Cin) ? xb[(long long)vl * a.Cin + min(c, a.Cin - 1)] : 0.f;
     if (!valid) t[0] = t[1] = t[2] = t[3] = 0.f;
     *reinterpret_cast<float4*>(sbase + (long long)min(v, N) * a.K * 4) = make_float4(t[0], t[1], t[2], t[3]);  // T_0 x = x
     slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);
