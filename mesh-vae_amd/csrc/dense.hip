@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_k4(const float* __restrict__ base, long lon
 
 constexpr int kGemmWaves = 8;
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool A_MASK>
 __global__ void __launch_bounds__(64 * kGemmWaves)
 k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float* __restrict__ Bm, long long sbk,
          long long sbn, float* __restrict__ C, int M, int N, int K, const float* __restrict__ bias, int act,
@@ -68,7 +68,7 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = ap[(long long)(k + t) * sak];
     }
-    if (mp) {
+    if constexpr (A_MASK) {  // compile-time: a run-time branch here fences each chunk's loads
       float mk[4];
       if constexpr (A_KC) {
         const float4 t = *reinterpret_cast<const float4*>(mp + k);
@@ -178,13 +178,16 @@ static int launch_gemm_ex(hipStream_t st, const float* A, long long sam, long lo
   int waves = cdiv(K, 16);  // one 16-chunk of K per wave at least
   waves = waves < 1 ? 1 : (waves > kGemmWaves ? kGemmWaves : waves);
 #define MVH_GEMM(AK, BK)                                                                                   \
-  hipLaunchKernelGGL((k_gemm16<AK, BK>), grid, dim3(64 * waves), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
+  do { if (a_mask) MVH_GEMM_M(AK, BK, true); else MVH_GEMM_M(AK, BK, false); } while (0)
+#define MVH_GEMM_M(AK, BK, MK)                                                                             \
+  hipLaunchKernelGGL((k_gemm16<AK, BK, MK>), grid, dim3(64 * waves), 0, st, A, sam, sak, Bm, sbk, sbn, C, M, N, K, bias, \
                      act, drop_u, p, a_mask, a_scale, ones_out)
   if (akc && bkc) MVH_GEMM(true, true);
   else if (akc) MVH_GEMM(true, false);
   else if (bkc) MVH_GEMM(false, true);
   else MVH_GEMM(false, false);
 #undef MVH_GEMM
+#undef MVH_GEMM_M
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
