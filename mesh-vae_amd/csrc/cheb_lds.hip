@@ -385,6 +385,17 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   // rows also go to the slab and every thread then gathers its pooled rows from LDS in the
   // operator's CSR order (the arithmetic of k_spmm<.., EXACT>).  Backward: ONLY the pooled rows are
   // stored (to `out`; no [B, N, C] gradient tensor); forward: `out` as usual + pooled rows to `pooled`.
+  int prow[VPT];  // pooled row of each own vertex, fetched in one branch-free batch (-1: not selected / no pooling)
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) prow[vi] = -1;
+  if (p_pool_inv) {
+#pragma unroll
+    for (int vi = 0; vi < VPT; ++vi) {
+      const int v = tid + vi * THREADS;
+      const int t = p_pool_inv[min(v, N - 1)];
+      prow[vi] = (v < N) ? t : -1;
+    }
+  }
   const bool scatter = p_pt_rowptr != nullptr;
   // (single slab: wait for the last gathers of u_1; two slabs: the rows go to the one nobody gathers from)
   if (scatter && !(kDB && a.K >= 2)) __syncthreads();
@@ -410,7 +421,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           (uint8_t)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
     if (!BWD && scatter) stage[v] = make_float4(o[0], o[1], o[2], o[3]);
     float* dst = outb + (long long)v * a.CO + s0;
-    const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
+    const int pr = prow[vi];  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
     if (vec_store) {
       *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -428,14 +439,29 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     __syncthreads();
     for (int c = tid; c < a.pt_rows; c += THREADS) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int e1 = p_pt_rowptr[c + 1];
-      for (int e = p_pt_rowptr[c]; e < e1; ++e) {
-        const float w = p_pt_val[e];
-        const float4 n = stage[p_pt_col[e]];
-        acc.x = __fadd_rn(acc.x, __fmul_rn(w, n.x));
-        acc.y = __fadd_rn(acc.y, __fmul_rn(w, n.y));
-        acc.z = __fadd_rn(acc.z, __fmul_rn(w, n.z));
-        acc.w = __fadd_rn(acc.w, __fmul_rn(w, n.w));
+      const int e0 = p_pt_rowptr[c], e1 = p_pt_rowptr[c + 1];
+      // four taps per round: their (col, val) loads and LDS reads are issued together (a tap-by-tap loop
+      // is one dependent global round trip per tap, ~12 of them per row of U^T); taps past the row
+      // end are clamped to a valid entry and given weight 0, so the sums stay in CSR order
+      for (int e = e0; e < e1; e += 4) {
+        float w[4];
+        int cc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ee = min(e + t, e1 - 1);
+          cc[t] = p_pt_col[ee];
+          w[t] = (e + t < e1) ? p_pt_val[ee] : 0.f;
+        }
+        float4 n[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) n[t] = stage[cc[t]];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc.x = __fadd_rn(acc.x, __fmul_rn(w[t], n[t].x));
+          acc.y = __fadd_rn(acc.y, __fmul_rn(w[t], n[t].y));
+          acc.z = __fadd_rn(acc.z, __fmul_rn(w[t], n[t].z));
+          acc.w = __fadd_rn(acc.w, __fmul_rn(w[t], n[t].w));
+        }
       }
       float* pb = BWD ? outb : p_pooled + (long long)mesh * a.pooled_bs * a.CO;
       *reinterpret_cast<float4*>(pb + (long long)c * a.CO + s0) = acc;
