@@ -257,14 +257,32 @@ k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const flo
     float s = 0.f;
     if (o < C) {
       const float* w = Wc + (long long)o * H;
-      for (int j = lane; j < H; j += 64) s = fmaf(hd[j], w[j], s);
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the row's loads are in flight together
+      int j = lane;
+      for (; j + 192 < H; j += 256) {
+        s = fmaf(hd[j], w[j], s);
+        s1 = fmaf(hd[j + 64], w[j + 64], s1);
+        s2 = fmaf(hd[j + 128], w[j + 128], s2);
+        s3 = fmaf(hd[j + 192], w[j + 192], s3);
+      }
+      for (; j < H; j += 64) s = fmaf(hd[j], w[j], s);
+      s = (s + s1) + (s2 + s3);
       s = wave_sum(s);
       if (lane == 0) outs[o] = s + bc[o];
     } else {
       const int zz = (o - C) % Z;
       const bool is_mu = (o - C) < Z;
       const float* w = (is_mu ? Wm : Wv) + (long long)zz * (C + H);
-      for (int j = lane; j < C + H; j += 64) s = fmaf(hy[j], w[j], s);
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int j = lane;
+      for (; j + 192 < C + H; j += 256) {
+        s = fmaf(hy[j], w[j], s);
+        s1 = fmaf(hy[j + 64], w[j + 64], s1);
+        s2 = fmaf(hy[j + 128], w[j + 128], s2);
+        s3 = fmaf(hy[j + 192], w[j + 192], s3);
+      }
+      for (; j < C + H; j += 64) s = fmaf(hy[j], w[j], s);
+      s = (s + s1) + (s2 + s3);
       s = wave_sum(s);
       if (lane == 0) outs[o] = s + (is_mu ? bm[zz] : bv[zz]);
     }
