@@ -80,8 +80,12 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   constexpr int STEPS_CT = TCT > 0 ? (VPT * TCT / 16) / (TCT / 64) : VPT * 4;  // 16-vertex steps per wave
   extern __shared__ __align__(16) unsigned char smem[];
   float4* slab = reinterpret_cast<float4*>(smem);   // [VS]; rows >= N stay zero
-  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]
-  const float* slabf = reinterpret_cast<const float*>(slab);
+  uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]   (kDB: the second slab instead)
+  // Small levels (TCT == 0): two slabs (t~_{k-1} gathered by everyone, t~_{k-2} touched only through the
+  // thread's own rows and overwritten in place by t~_k) and the neighbour ids in VGPRs, as in
+  // cheb_lds.hip: one barrier per order instead of two, no ELL image, no staging pass.
+  constexpr bool kDB = (TCT == 0) && (PW == 4);
+  float4* slabB = slab + VS;
 
   const int NS = (a.CP + 3) >> 2;
   const int QP = SPLIT ? a.CQtot / 4 : 1, CQT = SPLIT ? a.CQtot : CQ;
@@ -91,7 +95,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
 
-  {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
+  if constexpr (!kDB) {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
     const uint4 pad4 = make_uint4(pad, pad, pad, pad);
     const uint4* src = reinterpret_cast<const uint4*>(p_ell);
@@ -219,6 +223,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   constexpr bool kOvf = (TCT == 0);  // columns 8..11 of long rows (see cheb_lds.hip), small levels only
   uint32_t ovf0[kOvf ? VPT : 1], ovf1[kOvf ? VPT : 1];
   bool ovf_any[kOvf ? VPT : 1];
+  uint4 ids[kDB ? VPT : 1];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Pb = p_P + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
   const float* Pm = (p_Pmask && !a.mask_bits) ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
@@ -238,6 +243,11 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       const float deg = valid ? (float)(rinfo & 255u) : 0.f;
       ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
       const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+      if constexpr (kDB) {
+        const unsigned padi = (unsigned)N | ((unsigned)N << 16);
+        ids[vi] = valid ? reinterpret_cast<const uint4*>(p_ell)[vl] : make_uint4(padi, padi, padi, padi);
+        slabB[v] = make_float4(0.f, 0.f, 0.f, 0.f);  // t~_{-1} = 0
+      }
       if constexpr (kOvf) {
         const unsigned padw = (unsigned)N | ((unsigned)N << 16);
         ovf0[vi] = ovf1[vi] = padw;
@@ -318,11 +328,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   }
   __syncthreads();  // slab = t~_0, ELL staged
 
-  auto gather = [&](int v, int vi) {
+  auto gather = [&](int v, int vi, const float4* slab) {  // (shadows the kernel's `slab`: the slab to gather from)
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < PW / 4; ++q) {
-      const uint4 id = ellv[v * (PW / 4) + q];
+      uint4 id;
+      if constexpr (kDB) id = ids[vi];
+      else id = ellv[v * (PW / 4) + q];
       {
         const float4 n0 = slab[id.x & 0xffffu], n1 = slab[id.x >> 16];
         const float4 n2 = slab[id.y & 0xffffu], n3 = slab[id.y >> 16];
@@ -347,7 +359,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   };
 
   // dW tile of order k from the slab: 4 (x QH) MFMAs per 16 vertices, then one cross-block reduce
-  auto mfma_pass = [&](int k) {
+  auto mfma_pass = [&](int k, const float* slabf) {
     f32x4 acc[QH][4];
 #pragma unroll
     for (int h = 0; h < QH; ++h)
@@ -402,28 +414,48 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   };
 
-  mfma_pass(0);
-  for (int k = 1; k < a.K; ++k) {
-    const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
+  mfma_pass(0, reinterpret_cast<const float*>(slab));
+  if constexpr (kDB) {
+    float4* cur = slab;   // t~_{k-1}
+    float4* oth = slabB;  // t~_{k-2}, becomes t~_k (own rows only)
+    for (int k = 1; k < a.K; ++k) {
+      const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
 #pragma unroll
-    for (int vi = 0; vi < VPT; ++vi) {
-      const float4 g = gather(tid + vi * THREADS, vi);
-      const float kk = ka2[vi] * sc;
-      R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
-                          fmaf(kk, g.w, -R[vi].w));
+      for (int vi = 0; vi < VPT; ++vi) {
+        const int v = tid + vi * THREADS;
+        const float4 o = oth[v];
+        const float4 g = gather(v, vi, cur);
+        const float kk = ka2[vi] * sc;
+        oth[v] = make_float4(fmaf(kk, g.x, -o.x), fmaf(kk, g.y, -o.y), fmaf(kk, g.z, -o.z), fmaf(kk, g.w, -o.w));
+      }
+      __syncthreads();  // t~_k complete; every gather of t~_{k-1} and the previous MFMA pass (which read `cur`) done
+      mfma_pass(k, reinterpret_cast<const float*>(oth));
+      float4* t = cur;
+      cur = oth;
+      oth = t;
     }
-    __syncthreads();  // all reads of t~_{k-1} (gathers and the previous MFMA pass) are done
+  } else {
+    for (int k = 1; k < a.K; ++k) {
+      const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
 #pragma unroll
-    for (int vi = 0; vi < VPT; ++vi) {
-      const int v = tid + vi * THREADS;
-      const float4 old = slab[v];
-      slab[v] = R[vi];
-      R[vi] = old;
+      for (int vi = 0; vi < VPT; ++vi) {
+        const float4 g = gather(tid + vi * THREADS, vi, slab);
+        const float kk = ka2[vi] * sc;
+        R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
+                            fmaf(kk, g.w, -R[vi].w));
+      }
+      __syncthreads();  // all reads of t~_{k-1} (gathers and the previous MFMA pass) are done
+#pragma unroll
+      for (int vi = 0; vi < VPT; ++vi) {
+        const int v = tid + vi * THREADS;
+        const float4 old = slab[v];
+        slab[v] = R[vi];
+        R[vi] = old;
+      }
+      __syncthreads();
+      mfma_pass(k, reinterpret_cast<const float*>(slab));
     }
-    __syncthreads();
-    mfma_pass(k);
   }
-
 }
 
 // Sum the per-(mesh, wave) partial tiles in fixed order and scatter into dW [K][Cin][Cout] / db.
