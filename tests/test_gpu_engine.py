@@ -71,6 +71,32 @@ def test_trainstep_graph_equals_eager_and_learns():
     torch.testing.assert_close(params["graph"], params["eager"], rtol=1e-5, atol=1e-6)
 
 
+def test_trainstep_micro_batched_chains_equal_one_chain():
+    """n_micro = 2: the per-GPU batch as two independent chains, each enqueued by its own host thread on
+    its own stream, gradients averaged before Adam -- the same update as one chain (the loss is a mean over
+    meshes), up to fp32 summation order."""
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    B = 8
+    x = torch.randn(B, 162, 3, generator=torch.Generator().manual_seed(0))
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
+    params, losses = {}, {}
+    for n_micro in (1, 2):
+        net = _net(dev, dropout=0.0)
+        net.train()
+        step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=False, n_micro=n_micro)
+        assert step.n_micro == n_micro
+        step.load(x.to(dev), x.to(dev), y.to(dev))
+        torch.manual_seed(7)
+        for _ in range(4):
+            loss, correct, recon = step.step()
+        torch.cuda.synchronize()
+        params[n_micro], losses[n_micro] = step.flat.param.clone(), float(loss)
+        assert recon.shape == (B, 162, 3)
+    assert abs(losses[1] - losses[2]) <= 1e-5 * abs(losses[1]) + 1e-3
+    torch.testing.assert_close(params[2], params[1], rtol=1e-4, atol=2e-6)
+
+
 def test_flat_grads_equal_plain_autograd():
     from meshvae_hip.engine import FlatParams
     dev = torch.device("cuda:0")
