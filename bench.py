@@ -169,9 +169,10 @@ def main():
                          "graph executor serialises the side-stream branch, eager overlaps it and is ~15%% faster)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--micro", type=int, default=1, help="independent chains the per-GPU batch is pipelined over")
-    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
-                    help="untimed steps run for this long BEFORE the --warmup steps (clock / power-state ramp of a "
-                         "cold GPU: the first process on a fresh box was seen 25 %% slow otherwise); 0 disables")
+    ap.add_argument("--prewarm-steps", type=int, default=600,
+                    help="untimed steps run BEFORE the --warmup steps (clock / power-state ramp of a cold GPU: the "
+                         "first process on a fresh box was seen 25 %% slow otherwise).  A step COUNT, not a duration: "
+                         "every rank must issue the same number of gradient all-reduces.  0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
@@ -207,11 +208,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.prewarm_seconds > 0:          # not part of the contract's W warm-up steps: extra untimed work
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.prewarm_seconds:
-            for _ in range(20):
-                step.step()
+    for i in range(max(args.prewarm_steps, 0)):   # not part of the contract's W warm-up steps: extra untimed work
+        step.step()
+        if i % 50 == 49:
             torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step.step()
