@@ -256,7 +256,7 @@ def main():
                                "avg_launch_us": d["ms"] * 1e3, "algorithmic_bytes_per_launch": d["bytes"]}
             out["kernels"] = {k: {"avg_ms": v["ms"], "algo_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, 2)
+            out["cpu_baseline"] = cpu_baseline(B, 8)   # ~10-20 s of CPU work on 16 cores
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
