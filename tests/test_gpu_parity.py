@@ -454,3 +454,27 @@ def test_recon_postprocess_matches_oracle():
     torch.testing.assert_close(postprocess.euclidean_distances(gt, want_mesh), want_dist, rtol=1e-6, atol=1e-6)
     with pytest.raises(RuntimeError, match="MI355X only"):
         postprocess.reconstruct(out, std, mean, R, m, s)
+
+
+def test_integration_md_stub_runs_and_matches_oracle(ops_npz, topotiny_npz):
+    """The ctypes stub INTEGRATION.md shows to a reference maintainer is executed as written (only the
+    library path is made absolute) and its two functions are checked against the golden vectors."""
+    import re
+    from meshvae_hip import LIB_PATH
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libmeshvae_hip.so")', f'ctypes.CDLL({LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    dev = _dev()
+    case = "c_16_16_k6"
+    ei = _t(np.vstack([topotiny_npz["A0_row"], topotiny_npz["A0_col"]]).astype(np.int64), dev)
+    nrm = _t(topotiny_npz["A0_norm"], dev)
+    y = ns["cheb_conv_forward"](_t(ops_npz[f"{case}_x"], dev), ei, nrm, _t(ops_npz[f"{case}_w"], dev),
+                                _t(ops_npz[f"{case}_b"], dev))
+    torch.testing.assert_close(y.cpu(), _t(ops_npz[f"{case}_y"]), rtol=0, atol=FWD_ATOL)
+    idx = torch.from_numpy(np.vstack([topotiny_npz["U0_row"], topotiny_npz["U0_col"]]).astype(np.int64)).to(dev)
+    shape = tuple(int(v) for v in topotiny_npz["U0_shape"])
+    U = torch.sparse_coo_tensor(idx, _t(topotiny_npz["U0_val"], dev), shape, check_invariants=False)
+    torch.testing.assert_close(ns["surface_pool_forward"](_t(ops_npz["p_U0_x"], dev), U).cpu(), _t(ops_npz["p_U0_y"]),
+                               rtol=0, atol=0)
