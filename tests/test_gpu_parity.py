@@ -346,6 +346,13 @@ def test_full_model_train_step_matches_reference(which, model_tiny_npz, model_5k
     print(f"[{which}] worst relative gradient error = {worst:.3e}")
 
 
+def test_full_model_train_step_wide_kernel_shape(model_5k_npz, model_tiny_npz, monkeypatch):
+    """The 512 x 10 shape of the 5k-level conv kernels (MESHVAE_L0_CFG=1; default is 1024 x 5) against the
+    same reference gradients: both shapes stay correct (a semantically neutral edit once broke only one)."""
+    monkeypatch.setenv("MESHVAE_L0_CFG", "1")
+    test_full_model_train_step_matches_reference("5k", model_tiny_npz, model_5k_npz)
+
+
 def test_train_mode_dropout_statistics_and_determinism():
     dev = _dev()
     net = _build("tiny", dev)
