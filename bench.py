@@ -107,7 +107,7 @@ def kernel_rooflines(net, B, dev):
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/): rocprofv3
     cannot be driven from inside this process, so the counters are collected separately and read here."""
-    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic.json")
     try:
         table = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
