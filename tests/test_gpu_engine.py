@@ -161,3 +161,44 @@ def test_native_step_equals_module_path(gt_dtype):
         la = a(d, x.to(gt_dtype), y, m_type="test")
     lb = nat.forward_backward(x, x.to(gt_dtype), y, eps=None, backward=False)
     assert torch.equal(la[0], lb[0]) and torch.equal(la[2], lb[2]) and torch.equal(la[3][2], lb[3][2])
+
+
+@pytest.mark.parametrize("cfg_over, B", [
+    ({"polygon_order": [1, 2, 3]}, 5),                       # K = 1 and 2 layers, batch not a multiple of 8
+    ({"polygon_order": [6, 4, 6]}, 3),
+    ({"num_conv_filters": [5, 7, 7]}, 2),                    # channel counts outside the LDS kernels: general pipeline
+])
+def test_native_step_unusual_configs_match_module_path(cfg_over, B):
+    """Engine vs per-module autograd path on configurations the 5k default never exercises."""
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), dev)
+    cfg = dict(TINY_CFG, dropout=0.0, **cfg_over)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        nets.append(cheb_VAE(3, cfg, D, U, A, nn_).to(dev).train())
+    a, b = nets
+    x = torch.randn(B, 162, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    class Dt:
+        pass
+    d = Dt()
+    d.x, d.num_graphs, d.edge_index = x.reshape(-1, 3), B, None
+    a._eps_provider = lambda B_, Z_, dev_: eps
+    loss_a, _, recon_a, _, _ = a(d, x.double(), y, m_type="train")
+    loss_a.backward()
+    loss_b, _, recon_b, _, _ = NativeStep(b, B).forward_backward(x, x.double(), y, eps=eps)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(recon_b, recon_a.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss_b, loss_a.detach(), rtol=1e-9, atol=1e-6)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert float(pb.grad.abs().sum()) == 0.0, k
+        else:
+            err = float((pa.grad - pb.grad).norm()) / max(float(pa.grad.norm()), 1e-12)
+            assert err < 1e-4, (k, err)
