@@ -5,17 +5,19 @@ the template, converts it to the same uncoalesced torch sparse COO tensors the r
 hands to the model (model.py:24-32, 44-46), instantiates `cheb_VAE`, prints the parameter
 table and saves `initial_weight.pt` -- the caller-visible side effects of model.py:56-60.
 
-Hierarchy source: the reference generates it with psbody/open3d host code
-(mesh_operations.py), which is outside the hot path (SURVEY.md section 8(f) "next" #1) and not
-installable here.  Until that row is built, `config['topology']` must name an .npz holding
-the precomputed hierarchy (format of tests/golden/topology_5k.npz, produced from the
-reference's own generator by oracle/make_golden.py).
+Hierarchy source: as in the reference (model.py:36-42) the template OBJ named by
+`config['template']` is decimated `config['downsampling_factors']` times by this package's own
+`mesh_operations.generate_transform_matrices` (bit-identical to the reference's generator on the
+5k template, the tiny icosphere and the subdivided 20k template, tests/test_mesh_operations.py;
+~7 s at 5k vertices).  `config['topology']`, if given, names an .npz with a precomputed hierarchy
+instead (format of tests/golden/topology_5k.npz) and skips the generation.
 """
 import os
 
 import numpy as np
 import torch
 
+import mesh_operations
 from models.cheb_VAE import cheb_VAE
 
 
@@ -45,12 +47,17 @@ def load_topology(path, device):
 
 def get_model(config, device, model_type=None, save_init=True):
     topo = config.get('topology')
-    if not topo:
-        raise NotImplementedError(
-            "get_model: on-the-fly hierarchy generation (reference mesh_operations.py) is not built yet; "
-            "set config['topology'] to a precomputed hierarchy .npz (see oracle/make_golden.py)")
-    D_t, U_t, A_t, num_nodes = load_topology(topo, device)
-    num_feature = int(config.get('num_features', 3))
+    if topo:
+        D_t, U_t, A_t, num_nodes = load_topology(topo, device)
+        num_feature = int(config.get('num_features', 3))
+    else:
+        template_mesh = mesh_operations.Mesh(filename=config['template'])
+        num_feature = template_mesh.v.shape[1]
+        M, A, D, U = mesh_operations.generate_transform_matrices(template_mesh, config['downsampling_factors'])
+        D_t = [scipy_to_torch_sparse(d).to(device) for d in D]
+        U_t = [scipy_to_torch_sparse(u).to(device) for u in U]
+        A_t = [scipy_to_torch_sparse(a).to(device) for a in A]
+        num_nodes = [len(M[i].v) for i in range(len(M))]
     if model_type is None:
         model_type = config['type']
     if model_type != 'cheb_VAE':
