@@ -148,8 +148,10 @@ def test_get_model_side_effects(tmp_path, capsys):
     m = sp.coo_matrix(([1.0, 2.0, 3.0], ([2, 0, 1], [1, 1, 0])), shape=(3, 2))
     t = scipy_to_torch_sparse(m)
     assert t._indices().tolist() == [[2, 0, 1], [1, 1, 0]] and t._values().tolist() == [1.0, 2.0, 3.0]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError, match="template"):         # no precomputed hierarchy -> the reference's own key
         get_model(dict(cfg, topology=None), "cpu")
+    with pytest.raises(NotImplementedError):                # crecon's classifier is outside the hot path
+        get_model(cfg, "cpu", model_type="cheb_GCN")
 
 
 def test_recon_postprocess_oracle_matches_numpy():
