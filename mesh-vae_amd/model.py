@@ -19,6 +19,7 @@ import torch
 
 import mesh_operations
 from models.cheb_VAE import cheb_VAE
+from models.cheb_cls import cheb_GCN
 
 
 def scipy_to_torch_sparse(scp_matrix):
@@ -60,10 +61,15 @@ def get_model(config, device, model_type=None, save_init=True):
         num_nodes = [len(M[i].v) for i in range(len(M))]
     if model_type is None:
         model_type = config['type']
-    if model_type != 'cheb_VAE':
-        raise NotImplementedError(f"model type {model_type!r} is outside the hot path (only cheb_VAE is built)")
-    print('Using model: cheb_VAE')
-    net = cheb_VAE(num_feature, config, D_t, U_t, A_t, num_nodes, model=config.get('model', 'MSE_VAE')).to(device)
+    if model_type == 'cheb_VAE':
+        print('Using model: cheb_VAE')
+        net = cheb_VAE(num_feature, config, D_t, U_t, A_t, num_nodes, model=config.get('model', 'MSE_VAE')).to(device)
+    elif model_type == 'cheb_GCN':                     # crecon classifier on [x - recon_opp, x - recon] (model.py:62-65)
+        print('Using model: cheb_GCN')
+        net = cheb_GCN(num_feature * 2, config, D_t, U_t, A_t, num_nodes).to(device)
+    else:
+        # the reference returns an unbound `net` here (UnboundLocalError, model.py:118)
+        raise NotImplementedError(f"model type {model_type!r}: only cheb_VAE and cheb_GCN exist")
     for name, parameters in net.named_parameters():
         print(name, ':', parameters.size())
     if save_init:

@@ -22,6 +22,12 @@ Reference anchors (file:line under /root/reference):
   models/cheb_VAE.py:104-351 cheb_VAE                 -> OracleVAE
   logpdf.py:7-8,22-28  KLD / gaussian_nll / softclip  -> kld / gaussian_nll / softclip
   model.py:24-32       COO construction               -> coo_from_arrays
+  models/cheb_cls.py:22-27,55-114 Pool / cheb_GCN     -> surface_pool / gcn_init_state_dict, OracleGCN
+  crecon.py:160-198    estimate_diff                  -> estimate_diff
+cheb_GCN's convolution is torch-geometric 2.0.4's ChebConv (absent from the image); pyg_cheb_conv
+restates its published algorithm (the reference keeps an older copy of the same operator at
+nn/conv.py:390-521) and the golden vectors come from the reference's own cheb_cls.py / crecon.py
+run over oracle/refshim's stand-in for that class (oracle/make_golden_cls.py).
 """
 import math
 
@@ -244,6 +250,117 @@ class OracleVAE:
 
     def grads(self):
         return {k: v.grad for k, v in self.p.items() if v.grad is not None}
+
+
+# --------------------------------------------------------------------------- crecon classifier
+def pyg_cheb_conv(x, edge_index, lin_weights, bias=None):
+    """torch-geometric 2.0.4 ChebConv.forward with normalization='sym', lambda_max = 2 (the call
+    at models/cheb_cls.py:97; older in-tree copy of the operator: nn/conv.py:464-521).
+    lin_weights: K tensors [Cout, Cin] (one bias-free Linear per order).  The operator applied is
+    L^ = 2 (I - D^-1/2 A D^-1/2) / 2 - I, assembled as the published code does: the normalised edges,
+    then N self loops of +1 (get_laplacian), then N self loops of -1 (add_self_loops): the two
+    loop entries cancel only up to rounding, and are summed in that order here too."""
+    n = x.size(-2)
+    keep = edge_index[0] != edge_index[1]
+    ei = edge_index[:, keep]
+    w = torch.ones(ei.size(1), dtype=x.dtype)
+    deg = torch.zeros(n, dtype=x.dtype).scatter_add_(0, ei[0], w)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    w = -(dis[ei[0]] * w * dis[ei[1]])
+    loop = torch.arange(n)
+    src = torch.cat([ei[0], loop, loop])
+    dst = torch.cat([ei[1], loop, loop])
+    w = torch.cat([(2.0 * torch.cat([w, torch.ones(n, dtype=x.dtype)])) / 2.0, -torch.ones(n, dtype=x.dtype)])
+
+    def prop(t):                                             # [B, N, C]: gather at src, sum at dst
+        return propagate(t.transpose(0, 1), src, dst, w, n).transpose(0, 1)
+
+    t0 = t1 = x
+    out = F.linear(t0, lin_weights[0])
+    if len(lin_weights) > 1:
+        t1 = prop(x)
+        out = out + F.linear(t1, lin_weights[1])
+    for wk in lin_weights[2:]:
+        t2 = 2.0 * prop(t1) - t0
+        out = out + F.linear(t2, wk)
+        t0, t1 = t1, t2
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def gcn_init_state_dict(config, topo, num_features=6):
+    """models/cheb_cls.py:57-84,106-111 over PyG 2.0.4's constructors, drawing from the current
+    default generator in the same order: per conv, K glorot-uniform [Cout, Cin] draws when the
+    Linears are built and K more from ChebConv.reset_parameters (bias zero); enc_lin and cls_layer
+    with nn.Linear defaults; then cheb_GCN.reset_parameters: N(0,.1) on both linear weights and a
+    third glorot pass over the first n_layers convs.  state_dict order: conv bias before its lins."""
+    filters = [num_features] + list(config["num_conv_filters"])
+    K = config["polygon_order"]
+    sd = {}
+
+    def glorot(cout, cin):
+        a = math.sqrt(6.0 / (cout + cin))
+        return torch.empty(cout, cin).uniform_(-a, a)
+
+    n_conv = len(filters) - 2
+    for i in range(n_conv):
+        sd[f"cheb.{i}.bias"] = torch.zeros(filters[i + 1])
+        for _ in range(2):
+            for k in range(K[i]):
+                sd[f"cheb.{i}.lins.{k}.weight"] = glorot(filters[i + 1], filters[i])
+    flat = topo.D[-1][2][0] * filters[-2]
+    for name, fin, fout in (("enc_lin", flat, 128), ("cls_layer", 128, config["num_classes"])):
+        lin = torch.nn.Linear(fin, fout)
+        sd[name + ".weight"], sd[name + ".bias"] = lin.weight.detach(), lin.bias.detach()
+    sd["enc_lin.weight"] = torch.empty(128, flat).normal_(0, 0.1)
+    sd["cls_layer.weight"] = torch.empty(config["num_classes"], 128).normal_(0, 0.1)
+    for i in range(config["n_layers"]):
+        for k in range(K[i]):
+            sd[f"cheb.{i}.lins.{k}.weight"] = glorot(filters[i + 1], filters[i])
+    return sd
+
+
+class OracleGCN:
+    """Functional restatement of cheb_GCN.forward (models/cheb_cls.py:86-104) over a state_dict."""
+
+    def __init__(self, config, topo, state_dict, num_features=6, requires_grad=False):
+        self.n_layers = config["n_layers"]
+        self.filters = [num_features] + list(config["num_conv_filters"])
+        self.K = config["polygon_order"]
+        self.topo = topo
+        # cheb_cls.py:70-72: remove_self_loops on the raw adjacency indices
+        self.edge = [a[0][:, a[0][0] != a[0][1]] for a in topo.A]
+        self.p = {k: v.detach().clone().float().requires_grad_(requires_grad) for k, v in state_dict.items()}
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], -1, self.filters[0])
+        for i in range(self.n_layers):
+            lins = [self.p[f"cheb.{i}.lins.{k}.weight"] for k in range(self.K[i])]
+            x = F.relu(pyg_cheb_conv(x, self.edge[i], lins, self.p[f"cheb.{i}.bias"]))
+            x = surface_pool(x, *self.topo.D[i])
+        x = x.reshape(x.shape[0], -1)
+        x = F.relu(F.linear(x, self.p["enc_lin.weight"], self.p["enc_lin.bias"]))
+        return F.linear(x, self.p["cls_layer.weight"], self.p["cls_layer.bias"])
+
+    def grads(self):
+        return {k: v.grad for k, v in self.p.items() if v.grad is not None}
+
+
+def estimate_diff(vae, x, y, dtype):
+    """crecon.py:160-198 over an OracleVAE: encode, classify, condition on the true label ("train") or
+    the predicted one, decode the latent mean under that label and under the opposite one, and return
+    ([x - recon_opposite, x - recon] concatenated on channels, number of correct predictions)."""
+    with torch.no_grad():
+        h = vae.encoder(x)
+        pred = torch.argmax(vae.classifier(h), dim=1)
+        correct = torch.sum(pred == y).item()
+        hot = F.one_hot(y if dtype == "train" else pred, num_classes=2)
+        mu = F.linear(torch.cat([hot, h], -1), vae.p["z_mean.weight"], vae.p["z_mean.bias"])
+        recon = vae.sample(hot, mu)
+        recon_oppo = vae.sample(1 - hot, mu)
+        return torch.cat((x - recon_oppo, x - recon), dim=-1), correct
 
 
 def recon_postprocess(out, std, mean, R, m, s, gt_mesh):

@@ -13,7 +13,13 @@ the reference's call sites (requirements.txt pins):
 * torch-scatter==2.0.9   ``scatter_add`` / ``scatter(reduce='add'|'sum')``
   (nn/conv.py:363, :551) = zeros(dim_size).scatter_add_(dim, broadcast(index), src)
 * torch-geometric==2.0.4 ``utils.remove_self_loops`` (nn/conv.py:544)
-  = keep edges with row != col
+  = keep edges with row != col;  ``nn.conv.cheb_conv.ChebConv`` (models/cheb_cls.py:18,75
+  -- the crecon classifier's convolution): K bias-free ``Linear`` layers with glorot-uniform
+  weights [out, in] (drawn once at construction and again by ChebConv.reset_parameters), a zero
+  bias, and ``forward(x, edge_index)`` = sum_k lins[k](T_k) + bias with T_0 = x, T_1 = L^ x,
+  T_k = 2 L^ T_{k-1} - T_{k-2}; L^ is built per call as remove_self_loops -> get_laplacian('sym')
+  (edges -d^-1/2[row] d^-1/2[col], self loops +1) -> * 2/lambda_max (= 2.0) -> add_self_loops(-1);
+  messages are gathered at edge_index[0], summed at edge_index[1] over node_dim = -2
 * torch-sparse==0.6.13   ``SparseTensor`` (isinstance check only, nn/conv.py:152)
 * open3d (unpinned)      ``io.read_triangle_mesh`` (model.py:36) -> OBJ reader
 * psbody-mesh (unpinned) ``Mesh(v=, f=, filename=)`` (model.py:37) and
@@ -77,6 +83,105 @@ def remove_self_loops(edge_index, edge_attr=None):
     if edge_attr is None:
         return edge_index, None
     return edge_index, edge_attr[mask]
+
+
+def add_self_loops(edge_index, edge_attr=None, fill_value=1.0, num_nodes=None):
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    loop = torch.arange(0, n, dtype=torch.long, device=edge_index.device).unsqueeze(0).repeat(2, 1)
+    if edge_attr is not None:
+        fill = edge_attr.new_full((n,) + tuple(edge_attr.shape[1:]), fill_value)
+        edge_attr = torch.cat([edge_attr, fill], dim=0)
+    return torch.cat([edge_index, loop], dim=1), edge_attr
+
+
+def get_laplacian(edge_index, edge_weight=None, normalization=None, dtype=None, num_nodes=None):
+    if normalization != "sym":
+        raise NotImplementedError("stand-in covers ChebConv's default normalization='sym' only")
+    edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype, device=edge_index.device)
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    row, col = edge_index[0], edge_index[1]
+    deg = scatter_add(edge_weight, row, dim=0, dim_size=n)
+    deg_inv_sqrt = deg.pow_(-0.5)
+    deg_inv_sqrt.masked_fill_(deg_inv_sqrt == float("inf"), 0)
+    edge_weight = deg_inv_sqrt[row] * edge_weight * deg_inv_sqrt[col]
+    return add_self_loops(edge_index, -edge_weight, fill_value=1.0, num_nodes=n)   # L = I - A_norm
+
+
+class PygLinear(torch.nn.Module):
+    """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = torch.nn.Parameter(torch.Tensor(out_channels, in_channels))
+        self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = (6.0 / (self.weight.size(-2) + self.weight.size(-1))) ** 0.5      # inits.glorot
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
+class PygChebConv(torch.nn.Module):
+    """torch_geometric.nn.conv.ChebConv as published in 2.0.4, 'sym' normalisation, aggr='add',
+    flow source_to_target, node_dim=-2 (so [B, N, C] inputs broadcast over B)."""
+
+    def __init__(self, in_channels, out_channels, K, normalization="sym", bias=True):
+        super().__init__()
+        assert K > 0
+        assert normalization in [None, "sym", "rw"], "Invalid normalization"
+        self.in_channels, self.out_channels, self.normalization = in_channels, out_channels, normalization
+        self.lins = torch.nn.ModuleList([PygLinear(in_channels, out_channels) for _ in range(K)])
+        if bias:
+            self.bias = torch.nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+
+    def __norm__(self, edge_index, num_nodes, edge_weight, normalization, lambda_max, dtype=None):
+        edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)
+        edge_index, edge_weight = get_laplacian(edge_index, edge_weight, normalization, dtype, num_nodes)
+        edge_weight = (2.0 * edge_weight) / lambda_max
+        edge_weight.masked_fill_(edge_weight == float("inf"), 0)
+        return add_self_loops(edge_index, edge_weight, fill_value=-1.0, num_nodes=num_nodes)
+
+    @staticmethod
+    def propagate(edge_index, x, norm):
+        msg = norm.view(-1, 1) * x.index_select(-2, edge_index[0])
+        return scatter_add(msg, edge_index[1], dim=-2, dim_size=x.size(-2))
+
+    def forward(self, x, edge_index, edge_weight=None, batch=None, lambda_max=None):
+        if self.normalization != "sym" and lambda_max is None:
+            raise ValueError("You need to pass `lambda_max` to `forward() in`"
+                             "case the normalization is non-symmetric.")
+        if lambda_max is None:
+            lambda_max = torch.tensor(2.0, dtype=x.dtype, device=x.device)
+        edge_index, norm = self.__norm__(edge_index, x.size(-2), edge_weight, self.normalization,
+                                         lambda_max, dtype=x.dtype)
+        Tx_0, Tx_1 = x, x
+        out = self.lins[0](Tx_0)
+        if len(self.lins) > 1:
+            Tx_1 = self.propagate(edge_index, x, norm)
+            out = out + self.lins[1](Tx_1)
+        for lin in self.lins[2:]:
+            Tx_2 = self.propagate(edge_index, Tx_1, norm)
+            Tx_2 = 2.0 * Tx_2 - Tx_0
+            out = out + lin.forward(Tx_2)
+            Tx_0, Tx_1 = Tx_1, Tx_2
+        if self.bias is not None:
+            out += self.bias
+        return out
 
 
 # --------------------------------------------------------------------------- psbody / open3d
@@ -188,13 +293,17 @@ def install():
     _mod("torch_sparse", SparseTensor=type("SparseTensor", (), {}))
     tg = _mod("torch_geometric")
     tg.utils = _mod("torch_geometric.utils", remove_self_loops=remove_self_loops,
-                    add_self_loops=_unreachable("add_self_loops"), degree=_unreachable("degree"),
-                    get_laplacian=_unreachable("get_laplacian"))
+                    add_self_loops=add_self_loops, degree=_unreachable("degree"),
+                    get_laplacian=get_laplacian)
+    tg.data = _mod("torch_geometric.data", Dataset=torch.utils.data.Dataset, Data=_unreachable("Data"),
+                   DataLoader=_unreachable("DataLoader"))
+    if "torchvision" not in sys.modules:      # data.py:9 imports it and never uses it
+        tv = _mod("torchvision")
+        tv.transforms, tv.utils = _mod("torchvision.transforms"), _mod("torchvision.utils")
     tg.nn = _mod("torch_geometric.nn", dense_diff_pool=_unreachable("dense_diff_pool"),
                  global_sort_pool=_unreachable("global_sort_pool"))
     tg.nn.conv = _mod("torch_geometric.nn.conv")
-    tg.nn.conv.cheb_conv = _mod("torch_geometric.nn.conv.cheb_conv",
-                                ChebConv=type("ChebConv", (torch.nn.Module,), {}))
+    tg.nn.conv.cheb_conv = _mod("torch_geometric.nn.conv.cheb_conv", ChebConv=PygChebConv)
     o3d = _mod("open3d")
     o3d.io = _mod("open3d.io", read_triangle_mesh=lambda p: _O3DMesh(*read_obj(p)))
     o3d.geometry = _mod("open3d.geometry")

@@ -55,6 +55,16 @@ def model_20k_npz():
     return load_golden("model_20k.npz")
 
 
+@pytest.fixture(scope="session")
+def cls_tiny_npz():
+    return load_golden("cls_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def cls_5k_npz():
+    return load_golden("cls_5k.npz")
+
+
 # BASELINE configs[3] as SURVEY 8(d) pins it: 1->4 subdivision of the 5k template, 6 levels, K = 10
 CFG_20K = {"n_layers": 5, "num_conv_filters": [16, 16, 16, 32, 32, 32], "polygon_order": [10] * 6,
            "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}

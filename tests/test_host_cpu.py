@@ -150,8 +150,32 @@ def test_get_model_side_effects(tmp_path, capsys):
     assert t._indices().tolist() == [[2, 0, 1], [1, 1, 0]] and t._values().tolist() == [1.0, 2.0, 3.0]
     with pytest.raises(KeyError, match="template"):         # no precomputed hierarchy -> the reference's own key
         get_model(dict(cfg, topology=None), "cpu")
-    with pytest.raises(NotImplementedError):                # crecon's classifier is outside the hot path
-        get_model(cfg, "cpu", model_type="cheb_GCN")
+    with pytest.raises(NotImplementedError):
+        get_model(cfg, "cpu", model_type="saptial_conv")
+    # crecon's classifier (model.py:62-69): 2 x num_feature input channels, widens the caller's filter list
+    cfg2 = dict(cfg, num_conv_filters=list(TINY_CFG["num_conv_filters"]))
+    cls = get_model(cfg2, "cpu", model_type="cheb_GCN", save_init=False)
+    out = capsys.readouterr().out
+    assert "Using model: cheb_GCN" in out and "cheb.0.lins.0.weight : torch.Size([8, 6])" in out
+    assert cfg2["num_conv_filters"] == [6, 8, 16, 16] and cls.enc_lin.in_features == 11 * 16
+
+
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_classifier_init_is_bit_identical_to_reference(which, cls_tiny_npz, cls_5k_npz):
+    from model import load_topology
+    from models.cheb_cls import cheb_GCN
+    npz, cfg, topo = ((cls_tiny_npz, TINY_CFG, "topology_tiny.npz") if which == "tiny"
+                      else (cls_5k_npz, CFG_5K, "topology_5k.npz"))
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", topo), "cpu")
+    torch.manual_seed(666)
+    net = cheb_GCN(6, dict(cfg, num_conv_filters=list(cfg["num_conv_filters"])), D, U, A, nn_)
+    want, got = state_dict_from(npz), net.state_dict()
+    assert list(got.keys()) == list(want.keys())           # torch-geometric 2.0.4 layout: bias, lins.k.weight
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    net.load_state_dict(want)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(2, nn_[0], 6))
 
 
 def test_recon_postprocess_oracle_matches_numpy():

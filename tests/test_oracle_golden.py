@@ -182,3 +182,42 @@ def test_hires_20k_config_oracle_matches_reference(topo20k_npz, model_20k_npz):
         assert abs(float(grad.double().norm()) - gn) <= 1e-4 * gn + 1e-7, name
         torch.testing.assert_close(grad.reshape(-1)[:1024], _t(npz[f"train/grad_head/{name}"]), rtol=1e-3,
                                    atol=1e-4 * max(gn / max(grad.numel() ** 0.5, 1.0), 1e-3), msg=name)
+
+
+# --------------------------------------------------------------------------- crecon classifier
+@pytest.mark.parametrize("which", ["tiny", "5k"])
+def test_classifier_oracle_matches_reference(which, cls_tiny_npz, cls_5k_npz, topotiny_npz, topo5k_npz):
+    """cheb_GCN (models/cheb_cls.py) run by the reference over refshim's PyG-2.0.4 ChebConv: seed-666
+    initial weights bit-exact (names, order, values), logits / CE loss / all gradients at fp32 rounding."""
+    npz, cfg, topo = ((cls_tiny_npz, TINY_CFG, O.Topology(topotiny_npz)) if which == "tiny"
+                      else (cls_5k_npz, CFG_5K, O.Topology(topo5k_npz)))
+    torch.manual_seed(666)
+    sd = O.gcn_init_state_dict(cfg, topo)
+    want = state_dict_from(npz)
+    assert list(sd.keys()) == list(want.keys())
+    for k in want:
+        assert torch.equal(sd[k], want[k]), k
+    net = O.OracleGCN(cfg, topo, want, requires_grad=True)
+    logits = net.forward(_t(npz["x"]))
+    torch.testing.assert_close(logits, _t(npz["logits"]), rtol=1e-5, atol=1e-5)
+    loss = torch.nn.functional.cross_entropy(logits, _t(npz["label"]))
+    torch.testing.assert_close(loss, _t(npz["loss"]), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    g = net.grads()
+    assert sorted(g) == sorted(str(k) for k in npz["grad_names"])
+    for k in g:
+        w = _t(npz[f"grad/{k}"])
+        torch.testing.assert_close(g[k], w, rtol=1e-4, atol=1e-5 * max(1.0, float(w.abs().max())))
+
+
+def test_estimate_diff_oracle_matches_reference(cls_5k_npz, model_5k_npz, topo5k_npz):
+    """crecon.py:160-198 run by the reference on its seed-666 cheb_VAE (eval mode) vs the restatement."""
+    vae = O.OracleVAE(CFG_5K, O.Topology(topo5k_npz), state_dict_from(model_5k_npz))
+    x, label = _t(cls_5k_npz["diff/x"]), _t(cls_5k_npz["diff/label"])
+    assert np.array_equal(cls_5k_npz["diff/x"], model_5k_npz["x"])
+    for mode in ("train", "test"):
+        diff, correct = O.estimate_diff(vae, x, label, mode)
+        assert correct == int(cls_5k_npz[f"diff/{mode}_correct"])
+        assert diff.shape == (4, 4998, 6)
+        torch.testing.assert_close(diff, _t(cls_5k_npz[f"diff/{mode}"]), rtol=1e-5, atol=1e-5)
+    assert not np.array_equal(cls_5k_npz["diff/train"], cls_5k_npz["diff/test"])   # labels differ from predictions
