@@ -214,6 +214,30 @@ int mvh_recon_postprocess(mvh_stream_t stream, const float* recon, const float* 
                           const float* R, const float* m, const float* s, const float* gt, float* mesh_out,
                           float* dist_out, int32_t B, int32_t N);
 
+/* ---- around the step, input side: the Procrustes alignment of every mesh to the
+ * template when a dataset is built (data.py:144 -> utils.py:58-157, numpy double on the host there)
+ * as two device passes over meshes resident in HBM, with the 3x3 SVD between them left to the
+ * caller (LAPACK on 13 numbers per mesh).  All tensors fp64.
+ *   tmpl [N,3]: the standardised template mtx1 (centred, unit Frobenius norm; utils.py:136,147).
+ *   pts [B,N,3]; stats [B,13] = {centroid[3], norm2, M[3][3]} with M = mtx1^T ((pts-centroid)/norm2),
+ *   i.e. the matrix scipy's orthogonal_procrustes(mtx1, mtx2) decomposes (utils.py:151):
+ *   U,w,Vt = svd(M); R = U Vt; s = sum(w).
+ *   apply: aligned [B,N,3] = ((pts-centroid)/norm2) @ R^T * s (utils.py:152); disparity [B] or NULL
+ *   = sum((mtx1 - aligned)^2) (utils.py:155).  R [B,3,3] row-major, s [B]. */
+int mvh_procrustes_stats(mvh_stream_t stream, const double* tmpl, const double* pts, double* stats,
+                         int32_t B, int32_t N);
+int mvh_procrustes_apply(mvh_stream_t stream, const double* tmpl, const double* pts, const double* stats,
+                         const double* R, const double* s, double* aligned, double* disparity,
+                         int32_t B, int32_t N);
+
+/* MeshData.__getitem__ for a whole batch (data.py:103-111): x64[b] = (data[idx[b]] - mean) / std in fp64
+ * (the loss target x_gt) and x32 = its float cast (the network input), gathered from the device-resident
+ * aligned dataset data [n_meshes, n3] (n3 = N*3).  Bit-identical to the reference's torch CPU ops.
+ * idx [B] int64 on the device; mean, std [n3] fp64; x32 / x64 [B, n3], either may be NULL. */
+int mvh_gather_normalize(mvh_stream_t stream, const double* data, int64_t n_meshes, const int64_t* idx,
+                         const double* mean, const double* stdv, float* x32, double* x64, int32_t B,
+                         int64_t n3);
+
 /* ---- row F: cheb_VAE.forward (cheb_VAE.py:190-251) and loss.backward() (main.py:80) as one
  * native launch sequence.  `desc` describes the model the reference builds in
  * cheb_VAE.__init__ (cheb_VAE.py:106-172): filters = [num_features] + num_conv_filters,

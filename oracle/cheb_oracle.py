@@ -24,6 +24,8 @@ Reference anchors (file:line under /root/reference):
   model.py:24-32       COO construction               -> coo_from_arrays
   models/cheb_cls.py:22-27,55-114 Pool / cheb_GCN     -> surface_pool / gcn_init_state_dict, OracleGCN
   crecon.py:160-198    estimate_diff                  -> estimate_diff
+  utils.py:58-157      procrustes                     -> procrustes
+  data.py:103-111      MeshData.__getitem__ normalise -> normalize_items
 cheb_GCN's convolution is torch-geometric 2.0.4's ChebConv (absent from the image); pyg_cheb_conv
 restates its published algorithm (the reference keeps an older copy of the same operator at
 nn/conv.py:390-521) and the golden vectors come from the reference's own cheb_cls.py / crecon.py
@@ -373,6 +375,41 @@ def recon_postprocess(out, std, mean, R, m, s, gt_mesh):
     recon_mesh = torch.bmm(recon_mesh * s, R) + m.reshape(-1, 1, 3)
     dist = ((gt_mesh - recon_mesh) ** 2).sum(-1).sqrt()
     return recon_mesh, dist
+
+
+def procrustes(data1, data2):
+    """utils.py:120-157 in numpy double: centre both point sets, scale each to unit Frobenius norm, rotate
+    (or reflect) and rescale the second onto the first with scipy's orthogonal_procrustes
+    (U w Vt = svd(mtx1^T mtx2); R = U Vt; s = sum w).  Returns the reference's 4-tuple
+    (mtx1, mtx2, disparity, [R, norm2 / s, centroid2])."""
+    from scipy.linalg import svd
+    mtx1 = np.array(data1, dtype=np.double, copy=True)
+    mtx2 = np.array(data2, dtype=np.double, copy=True)
+    if mtx1.ndim != 2 or mtx2.ndim != 2:
+        raise ValueError("Input matrices must be two-dimensional")
+    if mtx1.shape != mtx2.shape:
+        raise ValueError("Input matrices must be of same shape")
+    if mtx1.size == 0:
+        raise ValueError("Input matrices must be >0 rows and >0 cols")
+    centroid2 = np.mean(mtx2, 0)
+    mtx1 -= np.mean(mtx1, 0)
+    mtx2 -= centroid2
+    norm1, norm2 = np.linalg.norm(mtx1), np.linalg.norm(mtx2)
+    if norm1 == 0 or norm2 == 0:
+        raise ValueError("Input matrices must contain >1 unique points")
+    mtx1 /= norm1
+    mtx2 /= norm2
+    u, w, vt = svd(mtx2.T.dot(mtx1).T)
+    R, s = u.dot(vt), w.sum()
+    mtx2 = np.dot(mtx2, R.T) * s
+    return mtx1, mtx2, np.sum(np.square(mtx1 - mtx2)), [R, norm2 / s, centroid2]
+
+
+def normalize_items(ori, mean, std):
+    """data.py:103-111 for a stack of aligned meshes [B,N,3] (numpy double): x_gt = (tensor(ori) - mean) /
+    std in fp64 and the network input = its .float().  Two torch ops; the reference has no fixture for it."""
+    x64 = (torch.tensor(ori) - torch.as_tensor(mean)) / torch.as_tensor(std)
+    return x64.float(), x64
 
 
 def log_sigma_const():

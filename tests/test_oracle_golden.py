@@ -221,3 +221,25 @@ def test_estimate_diff_oracle_matches_reference(cls_5k_npz, model_5k_npz, topo5k
         assert diff.shape == (4, 4998, 6)
         torch.testing.assert_close(diff, _t(cls_5k_npz[f"diff/{mode}"]), rtol=1e-5, atol=1e-5)
     assert not np.array_equal(cls_5k_npz["diff/train"], cls_5k_npz["diff/test"])   # labels differ from predictions
+
+
+# --------------------------------------------------------------------------- SURVEY 8(f) next #2, input side
+@pytest.mark.parametrize("tag", ["tiny", "5k"])
+def test_procrustes_oracle_matches_reference(tag):
+    """utils.procrustes run by the reference (oracle/make_golden_pre.py) vs the numpy restatement: same
+    LAPACK / BLAS calls, so agreement is at the last bits (one case is a reflection, det R = -1)."""
+    from conftest import load_golden
+    npz = load_golden("procrustes.npz")
+    for b, p in enumerate(npz[f"{tag}/pts"]):
+        mtx1, mtx2, disparity, (R, s, m) = O.procrustes(npz[f"{tag}/template"], p)
+        np.testing.assert_allclose(mtx1, npz[f"{tag}/mtx1"][b], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(mtx2, npz[f"{tag}/mtx2"][b], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(R, npz[f"{tag}/R"][b], rtol=0, atol=1e-13)
+        np.testing.assert_allclose([disparity, s], [npz[f"{tag}/disparity"][b], npz[f"{tag}/s"][b]], rtol=1e-12)
+        np.testing.assert_allclose(m, npz[f"{tag}/m"][b], rtol=1e-14)
+    if tag == "tiny":
+        assert np.linalg.det(npz["tiny/R"][2]) < 0
+        with pytest.raises(ValueError, match="same shape"):
+            O.procrustes(npz["tiny/template"], npz["tiny/pts"][0][:-1])
+        with pytest.raises(ValueError, match="unique points"):
+            O.procrustes(npz["tiny/template"], np.ones_like(npz["tiny/template"]))
