@@ -124,9 +124,9 @@ using namespace mvh;
 
 extern "C" int mvh_procrustes_stats(mvh_stream_t stream, const double* tmpl, const double* pts, double* stats,
                                     int32_t B, int32_t N) {
-  MVH_REQUIRE(tmpl && pts && stats, "procrustes_stats: null tensor");
   MVH_REQUIRE(B >= 0 && N > 0, "procrustes_stats: bad sizes B=%d N=%d", B, N);
-  if (B == 0) return MVH_OK;
+  if (B == 0) return MVH_OK;  // (empty tensors have null storage)
+  MVH_REQUIRE(tmpl && pts && stats, "procrustes_stats: null tensor");
   hipLaunchKernelGGL(k_procrustes_stats, dim3(B), dim3(kPreThreads), 0, (hipStream_t)stream, tmpl, pts, stats, N);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
@@ -135,9 +135,9 @@ extern "C" int mvh_procrustes_stats(mvh_stream_t stream, const double* tmpl, con
 extern "C" int mvh_procrustes_apply(mvh_stream_t stream, const double* tmpl, const double* pts, const double* stats,
                                     const double* R, const double* s, double* aligned, double* disparity,
                                     int32_t B, int32_t N) {
-  MVH_REQUIRE(tmpl && pts && stats && R && s && aligned, "procrustes_apply: null tensor");
   MVH_REQUIRE(B >= 0 && N > 0, "procrustes_apply: bad sizes B=%d N=%d", B, N);
   if (B == 0) return MVH_OK;
+  MVH_REQUIRE(tmpl && pts && stats && R && s && aligned, "procrustes_apply: null tensor");
   hipLaunchKernelGGL(k_procrustes_apply, dim3(B), dim3(kPreThreads), 0, (hipStream_t)stream, tmpl, pts, stats, R, s,
                      aligned, disparity, N);
   MVH_LAUNCH_CHECK();
@@ -147,11 +147,11 @@ extern "C" int mvh_procrustes_apply(mvh_stream_t stream, const double* tmpl, con
 extern "C" int mvh_gather_normalize(mvh_stream_t stream, const double* data, int64_t n_meshes, const int64_t* idx,
                                     const double* mean, const double* stdv, float* x32, double* x64, int32_t B,
                                     int64_t n3) {
-  MVH_REQUIRE(data && idx && mean && stdv, "gather_normalize: null tensor");
-  MVH_REQUIRE(x32 || x64, "gather_normalize: nothing to compute");
-  MVH_REQUIRE(B >= 0 && n3 > 0 && n_meshes > 0, "gather_normalize: bad sizes B=%d n3=%lld", B, (long long)n3);
+  MVH_REQUIRE(B >= 0 && n3 > 0 && n_meshes >= 0, "gather_normalize: bad sizes B=%d n3=%lld", B, (long long)n3);
   const long long total = (long long)B * n3;
   if (total == 0) return MVH_OK;
+  MVH_REQUIRE(data && idx && mean && stdv, "gather_normalize: null tensor");
+  MVH_REQUIRE(x32 || x64, "gather_normalize: nothing to compute");
   hipLaunchKernelGGL(k_gather_normalize, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, data,
                      (const long long*)idx, mean, stdv, x32, x64, (long long)n3, total);
   MVH_LAUNCH_CHECK();
