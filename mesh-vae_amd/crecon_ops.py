@@ -16,6 +16,22 @@ def classifier_(net, x):
     return torch.argmax(net.classifier(net.encoder(x)), dim=1)
 
 
+def estimate_diff_device(net, x, y, dtype):
+    """estimate_diff without the host read-back: -> (diff [B,N,6], #correct as a 0-d device tensor).
+    Nothing here synchronises, so the call can sit inside a hipGraph capture (engine.ClassifierStep)."""
+    with torch.no_grad():
+        h = net.encoder(x)
+        index_pred = torch.argmax(net.classifier(h), dim=1)
+        correct = torch.sum(index_pred == y)
+        sex_hot = F.one_hot(y if dtype == "train" else index_pred, num_classes=2)
+        x_mean = F_hip.linear(torch.cat([sex_hot.to(h.dtype), h], -1), net.z_mean.weight, net.z_mean.bias)
+        B = x_mean.shape[0]
+        # own-label and opposite-label decodes share one decoder pass (the decoder is per-mesh)
+        both = net.sample(torch.cat([sex_hot, 1 - sex_hot]), torch.cat([x_mean, x_mean]))
+        recon, recon_oppo = both[:B], both[B:]
+        return torch.cat((x - recon_oppo, x - recon), dim=-1), correct
+
+
 def estimate_diff(net, x, y, dtype):
     """([x - recon_opposite, x - recon] on the channel axis, #correct) -- crecon.py:160-198.
 
@@ -23,19 +39,8 @@ def estimate_diff(net, x, y, dtype):
     true label, anything else on the predicted one.  As in the reference the VAE runs under no_grad in
     whatever mode (`net.training`) the caller left it.
     """
-    ori = x
     if x.dim() == 2:
         x = x.reshape(1, -1, 3)
-        ori = x
         y = torch.as_tensor(y, device=x.device).unsqueeze(0)
-    with torch.no_grad():
-        h = net.encoder(x)
-        index_pred = torch.argmax(net.classifier(h), dim=1)
-        correct = torch.sum(index_pred == y).item()
-        sex_hot = F.one_hot(y if dtype == "train" else index_pred, num_classes=2)
-        x_mean = F_hip.linear(torch.cat([sex_hot.to(h.dtype), h], -1), net.z_mean.weight, net.z_mean.bias)
-        B = x_mean.shape[0]
-        # own-label and opposite-label decodes share one decoder pass (the decoder is per-mesh)
-        both = net.sample(torch.cat([sex_hot, 1 - sex_hot]), torch.cat([x_mean, x_mean]))
-        recon, recon_oppo = both[:B], both[B:]
-        return torch.cat((ori - recon_oppo, ori - recon), dim=-1), correct
+    diff, correct = estimate_diff_device(net, x, y, dtype)
+    return diff, correct.item()

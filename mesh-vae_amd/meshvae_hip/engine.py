@@ -274,6 +274,68 @@ class TrainStep:
         return self.out
 
 
+class ClassifierStep:
+    """One training step of the contrastive-reconstruction classifier (reference crecon.py:65-100):
+    estimate_diff of the frozen VAE -> cheb_GCN -> cross-entropy -> backward -> Adam (coupled L2,
+    crecon.py:311).  With `use_graph=True` the whole step is two hipGraphs over static buffers
+    (diff/forward/backward, then the fused Adam); eager it is the same launch sequence driven from
+    Python, which at these sizes is host-bound (tools/crecon_step.py).
+    """
+
+    def __init__(self, net, vae, batch, lr=1e-4, weight_decay=5e-4, use_graph=True, dtype="train"):
+        from crecon_ops import estimate_diff_device
+        self._diff = estimate_diff_device
+        self.net, self.vae, self.B, self.dtype = net, vae, batch, dtype
+        self.dev = next(net.parameters()).device
+        self.flat = FlatParams(net)
+        self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        n0 = vae.num_nodes[0]
+        self.x = torch.zeros(batch, n0, 3, device=self.dev)
+        self.label = torch.zeros(batch, dtype=torch.int64, device=self.dev)
+        self.use_graph, self.graph_fb, self.graph_opt, self.out = use_graph, None, None, None
+        vae._prepare()
+
+    def load(self, x_gt, label):
+        self.x.copy_(x_gt, non_blocking=True)          # .float() of the loader's fp64 x_gt (crecon.py:72)
+        self.label.copy_(label, non_blocking=True)
+
+    def _fwd_bwd(self):
+        diff, vae_correct = self._diff(self.vae, self.x, self.label, self.dtype)
+        self.flat.zero_grad()
+        pred = self.net(diff)
+        loss = torch.nn.functional.cross_entropy(pred, self.label)
+        loss.backward()
+        self.out = (loss.detach(), pred.detach(), vae_correct)
+
+    def capture(self, warmup=3):
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._fwd_bwd()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self._fwd_bwd()
+        self.graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_opt):
+            self.opt.step(1.0)
+        torch.cuda.synchronize(self.dev)
+
+    def step(self):
+        """-> (loss, logits [B, num_classes], #meshes the VAE's own head classified correctly), device tensors."""
+        if self.use_graph:
+            if self.graph_fb is None:
+                self.capture()
+            self.graph_fb.replay()
+            self.graph_opt.replay()
+        else:
+            self._fwd_bwd()
+            self.opt.step(1.0)
+        return self.out
+
+
 class NativeStep:
     """cheb_VAE.forward + loss.backward() through mvh_vae_forward / mvh_vae_backward: every
     kernel is enqueued from C++, activations live in one workspace, parameter gradients are

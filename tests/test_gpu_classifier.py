@@ -137,3 +137,53 @@ def test_estimate_diff_matches_reference(cls_5k_npz, model_5k_npz):
         la = net(estimate_diff(vae, x, label, "train")[0])
         lb = net(estimate_diff(vae, x, label, "test")[0])
     assert torch.isfinite(la).all() and torch.isfinite(lb).all() and not torch.equal(la, lb)
+
+
+def test_classifier_step_graph_equals_eager_and_module_path():
+    """engine.ClassifierStep: the hipGraph replay is bitwise equal to the eager launch sequence, and both follow
+    the plain module path (estimate_diff -> cheb_GCN -> CrossEntropyLoss -> torch.optim.Adam, crecon.py:65-100)."""
+    from crecon_ops import estimate_diff
+    from meshvae_hip.engine import ClassifierStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = _dev()
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), dev)
+    torch.manual_seed(666)
+    vae = cheb_VAE(3, TINY_CFG, D, U, A, nn_, model="optimal_sigma_VAE").to(dev).eval()   # deterministic VAE
+    B = 8
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(B, nn_[0], 3, generator=g).to(dev) for _ in range(4)]
+    ys = [torch.randint(0, 2, (B,), generator=g).to(dev) for _ in range(4)]
+
+    def run(mode):
+        net = _classifier("tiny", dev)
+        losses = []
+        if mode == "module":
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+            for x, y in zip(xs, ys):
+                diff, _ = estimate_diff(vae, x, y, "train")
+                opt.zero_grad()
+                loss = torch.nn.CrossEntropyLoss()(net(diff), y)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+        else:
+            cs = ClassifierStep(net, vae, B, lr=1e-3, weight_decay=5e-4, use_graph=(mode == "graph"))
+            if mode == "graph":
+                cs.load(xs[0], ys[0])
+                cs.capture()                       # warm-up steps do not touch the weights (no optimizer inside)
+            for x, y in zip(xs, ys):
+                cs.load(x, y)
+                loss, logits, vae_correct = cs.step()
+                assert logits.shape == (B, 2) and 0 <= int(vae_correct) <= B
+                losses.append(loss.clone())
+        return torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+
+    l_e, sd_e = run("eager")
+    l_g, sd_g = run("graph")
+    l_m, sd_m = run("module")
+    assert torch.equal(l_e, l_g) and all(torch.equal(sd_e[k], sd_g[k]) for k in sd_e)
+    torch.testing.assert_close(l_e, l_m, rtol=1e-5, atol=1e-6)
+    for k in sd_m:
+        torch.testing.assert_close(sd_e[k], sd_m[k], rtol=1e-4, atol=2e-5, msg=k)
+    assert not torch.equal(l_e[0], l_e[-1])

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--engine", choices=["module", "eager", "graph"], default="module",
+                    help="module: torch.optim.Adam over the autograd modules; eager/graph: engine.ClassifierStep")
     a = ap.parse_args()
     from crecon_ops import estimate_diff
     from model import load_topology
@@ -36,7 +38,14 @@ def main():
     x = torch.randn(a.batch, nn_[0], 3, device=dev)
     y = (torch.arange(a.batch, device=dev) % 2)
 
+    if a.engine != "module":
+        from meshvae_hip.engine import ClassifierStep
+        cs = ClassifierStep(net, vae, a.batch, use_graph=(a.engine == "graph"))
+        cs.load(x, y)
+
     def step():
+        if a.engine != "module":
+            return cs.step()[0]
         diff, _ = estimate_diff(vae, x, y, "train")
         opt.zero_grad()
         loss = crit(net(diff), y)
@@ -52,7 +61,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    print(f"crecon classifier step: B={a.batch} {ms:.3f} ms/step  {a.batch / ms * 1e3:.0f} meshes/s  loss={float(loss):.4f}")
+    print(f"crecon classifier step [{a.engine}]: B={a.batch} {ms:.3f} ms/step  {a.batch / ms * 1e3:.0f} meshes/s  loss={float(loss.detach()):.4f}")
 
 
 if __name__ == "__main__":
