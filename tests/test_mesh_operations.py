@@ -101,3 +101,24 @@ def test_get_model_builds_the_hierarchy_from_the_template(tmp_path, topotiny_npz
     for a, b in zip(net.upsample_matrices, U_t):
         assert torch.equal(a._indices(), b._indices()) and torch.equal(a._values(), b._values())
     assert (tmp_path / "initial_weight.pt").exists()
+
+
+def test_pruned_closest_point_equals_exhaustive_scan():
+    """nearest_on_surface's candidate pruning returns exactly what the all-triangles scan returns: faces, region
+    codes and hit points, for points on, near and far from the surface (ties resolve to the lowest face)."""
+    z = load_golden("template_5k.npz")
+    mesh = mo.Mesh(v=z["verts"], f=z["faces"])
+    g = np.random.default_rng(0)
+    v = mesh.v
+    pick = g.choice(len(v), 120, replace=False)
+    span = np.ptp(v, axis=0).max()
+    pts = np.concatenate([v[pick[:40]],                                            # exactly on vertices (ties)
+                          v[pick[40:80]] + g.standard_normal((40, 3)) * 0.01 * span,  # near the surface
+                          v[pick[80:]] + g.standard_normal((40, 3)) * 2.0 * span])    # far away
+    sf = np.asarray(mesh.f, dtype=np.int64)
+    a, b, c = v[sf[:, 0]], v[sf[:, 1]], v[sf[:, 2]]
+    f0, r0, h0 = mo._nearest_exhaustive(pts, a, b - a, c - a, b, c)
+    f1, r1, h1 = mo.nearest_on_surface(mesh, pts)
+    f2, r2, h2 = mo.nearest_on_surface(mesh, pts, chunk_pairs=50)                  # many small chunks
+    for f, r, h in ((f1, r1, h1), (f2, r2, h2)):
+        assert np.array_equal(f, f0) and np.array_equal(r, r0) and np.array_equal(h, h0)
