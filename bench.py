@@ -22,6 +22,12 @@ for _p in (ROOT, os.path.join(ROOT, "mesh-vae_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# The step runs on three HIP streams (main chain + two weight-gradient lanes); a process group adds RCCL's.
+# The HIP runtime multiplexes streams onto 4 hardware queues by default, and with the extra streams the
+# gradient lanes end up sharing the main chain's queue: measured 0.83 ms/step instead of 0.63 with a 1-rank
+# RCCL group (tools/dist_overhead.sh, dist_overhead2.sh).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -180,8 +186,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") == "1"   # 1-rank rehearsal of the RCCL path
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -204,7 +212,7 @@ def main():
         step.capture()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -220,7 +228,7 @@ def main():
         step.step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -260,7 +268,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, 8)   # ~10-20 s of CPU work on 16 cores
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,6 +7,12 @@ tensor, the call raises.
 import ctypes
 import os
 
+# More hardware queues than the HIP default of 4: the native step uses three streams and a process group adds
+# RCCL's; once streams share a queue the weight-gradient lanes serialise behind the main chain (+30 % step time,
+# tools/dist_overhead2.sh).  Only effective if the HIP runtime has not been initialised yet (import this
+# package, or set the variable, before the first torch.cuda call).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MESHVAE_LIB lets a benchmark A/B two builds of the library in one process-per-run session
 LIB_PATH = os.environ.get("MESHVAE_LIB") or os.path.join(_HERE, "libmeshvae_hip.so")

@@ -8,6 +8,8 @@ per step, followed by the 1/world scale folded into the optimizer kernel.  Param
 gradients live in two contiguous buffers so no bucketing copies exist; `dec_lin_1` (never
 used, cheb_VAE.py:165) stays in the buffers with a zero gradient.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -58,7 +60,10 @@ class FlatParams:
 
     def all_reduce(self, group=None):
         """Sum all-reduce of the flat gradient buffer (one collective per step)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (
+                dist.get_world_size(group) > 1 or os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") == "1"):
+            # (the env switch runs the collective on a 1-rank group too: the only way to rehearse the RCCL
+            # stream hand-over of the multi-GPU path on a one-GPU box)
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             return dist.get_world_size(group)
         return 1
