@@ -283,6 +283,15 @@ int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const floa
                      const float* recon, const float* y_hat, const float* mu, const float* logvar,
                      void* ws, size_t ws_bytes, mvh_stream_t side_stream /* NULL = internal */);
 
+/* Data-parallel overlap: make `stream` wait until the DENSE-layer weight gradients written by the
+ * most recent mvh_vae_backward issued from this host thread on the current device are final -- classifier_layer,
+ * z_mean, z_log_var, enc_lin, dec_lin, dec_lin_1, dec_lin_2: 98 % of the parameter bytes at default.cfg, and they
+ * are complete before the encoder half of the backward starts.  A caller that keeps those parameters contiguous
+ * can all-reduce them on `stream` underneath the rest of the backward and only the convolution weights
+ * (80 KB) after it.  The reference has no distributed code; this replaces nothing there.  Error if no backward
+ * was issued yet (or the last one ran inside a stream capture, where no event is recorded). */
+int mvh_vae_wait_dense_grads(mvh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,8 @@ struct SideStream {
   hipEvent_t ev[64];
   int n_ev = 0;
   int next_ev = 0;
+  hipEvent_t dense_done = nullptr;  // recorded after the dense-layer weight gradients of the last backward
+  bool dense_recorded = false;
 };
 
 // (a kernel rather than hipMemsetAsync: memset nodes on a forked stream crashed graph instantiation)
@@ -152,6 +154,7 @@ static SideStream* side_for_device() {
     if (hipStreamCreateWithFlags(&s.dense, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming) != hipSuccess) return nullptr;
     s.n_ev = 64;
   }
   return &s;
@@ -426,6 +429,14 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                        (long long)p.H * (p.C + p.Z));
     hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, dstream, G[ix.dl1B()], (long long)p.H);
     MVH_LAUNCH_CHECK();
+    // every dense-layer gradient (98 % of the parameter bytes) is final from here on: a data-parallel caller
+    // starts their all-reduce now, under the encoder half of the backward (mvh_vae_wait_dense_grads).
+    // Not inside a stream capture: the event would become part of the graph.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+      MVH_HIP(hipEventRecord(side->dense_done, dstream));
+      side->dense_recorded = true;
+    }
   }
   // ---- encoder stages, last to first.  g_encP[i] is the gradient of the POOLED conv output; the
   // one-hot un-pooling is folded into the loads of the dW / dX kernels (no scatter launch, no
@@ -508,6 +519,14 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     ev = (ev + 1) % side->n_ev;
   }
   TRY(launch_dw_reduce_all(main, red));  // every deferred dW / db in one launch
+  return MVH_OK;
+}
+
+extern "C" int mvh_vae_wait_dense_grads(mvh_stream_t stream) {
+  SideStream* side = side_for_device();
+  MVH_REQUIRE(side != nullptr, "vae_wait_dense_grads: no device");
+  MVH_REQUIRE(side->dense_recorded, "vae_wait_dense_grads: no mvh_vae_backward was issued from this thread on this device");
+  MVH_HIP(hipStreamWaitEvent((hipStream_t)stream, side->dense_done, 0));
   return MVH_OK;
 }
 

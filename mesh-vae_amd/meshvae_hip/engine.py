@@ -58,6 +58,16 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def conv_dense_split(self):
+        """Offset (floats) where the dense-layer parameters start in the flat buffers: cheb_VAE registers its
+        ChebConv lists first and the nn.Linear layers after them (cheb_VAE.py:121-166), so the dense gradients
+        -- final half-way through the backward -- are one contiguous tail.  None if the order is different."""
+        conv = [n.startswith(("cheb.", "cheb_dec.")) for n in self.names]
+        k = conv.index(False) if False in conv else len(conv)
+        if k == 0 or k == len(conv) or any(conv[k:]):
+            return None
+        return self.offsets[k]
+
     def all_reduce(self, group=None):
         """Sum all-reduce of the flat gradient buffer (one collective per step)."""
         if dist.is_available() and dist.is_initialized() and (
@@ -132,6 +142,7 @@ class TrainStep:
         self.use_graph = use_graph
         self.graph_fb = self.graph_opt = None
         self._out = None
+        self._comm = None      # stream of the overlapped dense-gradient all-reduce (created on first use)
         net._eps_provider = lambda B, Z, device: self.eps      # static buffer (graph-safe)
         net._prepare()                                         # topology upload must precede any capture
         # native=True: the whole forward+backward is one C++ launch sequence (mvh_vae_forward/backward);
@@ -274,9 +285,42 @@ class TrainStep:
             self.graph_opt.replay()
         else:
             self._fwd_bwd()
-            self.flat.all_reduce(self.group)
+            if not self._all_reduce_overlapped():
+                self.flat.all_reduce(self.group)
             self.opt.step(scale)
         return self.out
+
+    def _all_reduce_overlapped(self):
+        """Two-bucket gradient all-reduce of the eager native step: the dense-layer gradients (98 % of the bytes,
+        one contiguous tail of the flat buffer) are final before the encoder half of the backward runs, so their
+        collective is issued on its own stream behind the event the library records at that point
+        (mvh_vae_wait_dense_grads) and runs underneath the rest of the backward; only the convolution weights
+        (80 KB at default.cfg) are reduced after it.  The host has enqueued the whole backward long before the GPU
+        gets there, so issuing the collective "late" from the host still starts it early on the device.  Same
+        call order on every rank (dense bucket, then conv bucket).
+        OPT-IN (MESHVAE_AR_OVERLAP=1).  Measured on one GPU with a 1-rank RCCL group (tools/dist_overhead3.sh):
+        the second collective costs 17 us of fixed overhead per step (0.664 vs 0.647 ms), so it pays only where
+        the 2.8 MB all-reduce takes clearly longer than an 80 KB one plus that -- which this one-GPU pool cannot
+        measure; the default stays ONE collective after the backward."""
+        if not (dist.is_available() and dist.is_initialized()) or self.native is None or self.n_micro != 1:
+            return False
+        if dist.get_world_size(self.group) <= 1 and os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") != "1":
+            return False
+        if os.environ.get("MESHVAE_AR_OVERLAP") != "1":
+            return False
+        split = self.flat.conv_dense_split()
+        if split is None:
+            return False
+        cur = torch.cuda.current_stream(self.dev)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(self.dev)
+        with torch.cuda.device(self.dev):
+            check(lib().mvh_vae_wait_dense_grads(self._comm.cuda_stream))
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(self.flat.grad[split:], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.flat.grad[:split], op=dist.ReduceOp.SUM, group=self.group)
+            cur.wait_stream(self._comm)
+        return True
 
 
 class ClassifierStep:

@@ -202,3 +202,60 @@ def test_native_step_unusual_configs_match_module_path(cfg_over, B):
         else:
             err = float((pa.grad - pb.grad).norm()) / max(float(pa.grad.norm()), 1e-12)
             assert err < 1e-4, (k, err)
+
+
+def test_dense_gradients_are_final_at_the_library_event():
+    """The overlapped all-reduce (engine.TrainStep._all_reduce_overlapped) reads the dense-layer gradients on
+    another stream as soon as the event behind mvh_vae_wait_dense_grads fires, while the encoder half of the
+    backward is still running.  Poison the gradient buffer, snapshot the dense tail on a second stream behind
+    that event, and require the snapshot to equal the final gradients (5k model, so the backward is long)."""
+    import threading
+
+    import meshvae_hip
+    from conftest import CFG_5K
+    from meshvae_hip.engine import TrainStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_5k.npz"), dev)
+    torch.manual_seed(666)
+    net = cheb_VAE(3, CFG_5K, D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
+    B = 16
+    step = TrainStep(net, B, use_graph=False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, nn_[0], 3, generator=g)
+    step.load(x, x, torch.nn.functional.one_hot(torch.arange(B) % 2, 2))
+    flat = step.flat
+    split = flat.conv_dense_split()
+    k = flat.offsets.index(split)
+    assert flat.names[k] == "classifier_layer.weight" and all(n.startswith("cheb") for n in flat.names[:k])
+    assert (flat.numel - split) * 4 > 0.95 * flat.numel * 4          # the tail is almost all of the bytes
+    comm = torch.cuda.Stream(dev)
+    snap = torch.empty_like(flat.grad[split:])
+    for _ in range(3):
+        flat.grad.fill_(float("nan"))
+        step._draw_eps()
+        step._fwd_bwd()
+        meshvae_hip.check(meshvae_hip.lib().mvh_vae_wait_dense_grads(comm.cuda_stream))
+        with torch.cuda.stream(comm):
+            snap.copy_(flat.grad[split:])
+        torch.cuda.synchronize()
+        for p, off in zip(flat.params[k:], flat.offsets[k:]):
+            got = snap[off - split:off - split + p.numel()]
+            assert torch.isfinite(got).all(), "dense gradient read before it was written"
+            assert torch.equal(got, p.grad.reshape(-1))
+        for p in flat.params[:k]:
+            assert torch.isfinite(p.grad).all()
+    flat.grad.zero_()
+    # a thread that never ran a backward has no event to wait for
+    err = []
+
+    def other():
+        try:
+            meshvae_hip.check(meshvae_hip.lib().mvh_vae_wait_dense_grads(comm.cuda_stream))
+        except meshvae_hip.MeshVaeHipError as e:
+            err.append(str(e))
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert err and "no mvh_vae_backward" in err[0]

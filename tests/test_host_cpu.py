@@ -207,3 +207,18 @@ def test_scheduled_lr_follows_reference_table():
     for epoch in (1, 10, 11, 20, 21, 30, 31, 300):
         assert scheduled_lr(cfg, epoch, 8e-3) == ref(epoch, 8e-3)
     assert scheduled_lr({}, 5, 3e-3) == 3e-3
+
+
+def test_flat_buffer_splits_into_conv_head_and_dense_tail():
+    """engine.FlatParams.conv_dense_split: the bucket boundary of the overlapped gradient all-reduce."""
+    from meshvae_hip.engine import FlatParams
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), "cpu")
+    net = cheb_VAE(3, TINY_CFG, D, U, A, nn_)
+    flat = FlatParams(net)
+    split = flat.conv_dense_split()
+    k = flat.offsets.index(split)
+    assert flat.names[k] == "classifier_layer.weight" and flat.names[k - 1].startswith("cheb_dec.")
+    assert split % FlatParams.ALIGN == 0 and 0 < split < flat.numel
+    assert FlatParams(torch.nn.Linear(3, 4)).conv_dense_split() is None        # no conv head: no split
