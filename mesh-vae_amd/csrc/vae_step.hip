@@ -150,8 +150,12 @@ static SideStream* side_for_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream& s = side[dev];
   if (!s.stream) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipStreamCreateWithFlags(&s.dense, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // MESHVAE_SIDE_PRIO=low|high: queue priority of the two weight-gradient lanes relative to the caller's stream
+    int lo = 0, hi = 0, prio = 0;
+    const char* pe = getenv("MESHVAE_SIDE_PRIO");
+    if (pe && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = (pe[0] == 'l') ? lo : (pe[0] == 'h') ? hi : 0;
+    if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithPriority(&s.dense, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming) != hipSuccess) return nullptr;
