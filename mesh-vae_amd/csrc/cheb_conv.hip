@@ -165,6 +165,50 @@ k_gstack_rows(const float* __restrict__ dout, const float* __restrict__ out, con
   *reinterpret_cast<float4*>(g0 + r * Cin + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// 16 -> 16 channels on a big level (the 20k-vertex level of BASELINE configs[3]: 82 MB of dout in, 819 MB of
+// G stack out): G_k^T = W_k dpre^T on the matrix pipe.  A = W_k [ci x co], B = dpre^T [co x 16 rows]; the
+// reduction slot (s, q) stands for co = 4 q + s so that both operands are 16-byte loads, and the result
+// C[ci = 4 q + j][row = lane % 16] leaves as one float4 per lane: every wave load and store is 1 KB
+// contiguous.  (The one-thread-per-row kernel reads dout with a 64-byte lane stride: 985 us here.)
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
+
+template <int KMAX, bool RELU>
+__global__ void __launch_bounds__(256)
+k_gstack_mfma16(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ W,
+                float* __restrict__ G, float* __restrict__ g0, long long rows, int K, long long blocks_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  float4 wa[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    wa[k] = k < K ? *reinterpret_cast<const float4*>(W + ((long long)k * 16 + m) * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long nblk = (rows + 15) / 16;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  const long long b_end = min(nblk, (wid + 1) * blocks_per_wave);
+  for (long long blk = wid * blocks_per_wave; blk < b_end; ++blk) {
+    const long long row_raw = blk * 16 + m;
+    const long long row = min(row_raw, rows - 1);
+    float4 d = *reinterpret_cast<const float4*>(dout + row * 16 + 4 * q);
+    if constexpr (RELU) {
+      const float4 o = *reinterpret_cast<const float4*>(out + row * 16 + 4 * q);
+      d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        f32x4_g acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].x, d.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].y, d.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].z, d.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].w, d.w, acc, 0, 0, 0);
+        float* dst = (k == 0 ? g0 : G + (long long)k * rows * 16);
+        if (row_raw < rows)
+          *reinterpret_cast<float4*>(dst + row_raw * 16 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+  }
+}
+
 static int launch_gstack(hipStream_t st, const float* dout, const float* out, const float* W, float* G,
                          float* g0, long long rows, int Cin, int Cout, int K, int act) {
   if (K == 1 && (Cin & 3) == 0 && ((uintptr_t)g0 & 15) == 0 && (Cout == 3 || Cout == 4)) {
@@ -173,6 +217,22 @@ static int launch_gstack(hipStream_t st, const float* dout, const float* out, co
       hipLaunchKernelGGL((k_gstack_rows<3>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
     else
       hipLaunchKernelGGL((k_gstack_rows<4>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
+    MVH_LAUNCH_CHECK();
+    return MVH_OK;
+  }
+  static const char* no_mfma = getenv("MESHVAE_NO_GSTACK_MFMA");
+  if (Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !(no_mfma && no_mfma[0] == '1') &&
+      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)W | (uintptr_t)G | (uintptr_t)g0) & 15) == 0) {
+    const long long nblk = (rows + 15) / 16;
+    const long long waves = min(nblk, 8192ll);
+    const long long bpw = (nblk + waves - 1) / waves;
+    const int g = (int)((nblk + bpw * 4 - 1) / (bpw * 4));
+    const bool relu = act == MVH_ACT_RELU;
+#define MVH_GM(KM, R) \
+  hipLaunchKernelGGL((k_gstack_mfma16<KM, R>), dim3(g), dim3(256), 0, st, dout, out, W, G, g0, rows, K, bpw)
+    if (K <= 6) { if (relu) MVH_GM(6, true); else MVH_GM(6, false); }
+    else { if (relu) MVH_GM(12, true); else MVH_GM(12, false); }
+#undef MVH_GM
     MVH_LAUNCH_CHECK();
     return MVH_OK;
   }
@@ -277,15 +337,127 @@ k_cheb_dw(const float* __restrict__ x, const float* __restrict__ tx, const float
 }
 
 // out[i] = sum_g partial[g][i] in fixed order; first n_w entries go to dW, the rest to db.
+// 64 outputs per block; its 4 waves take interleaved quarters of the G partials with four independent chains
+// each (512 dependent loads per output in one thread took 120 us at the 20k level), combined through LDS.
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float* __restrict__ partial, int G, int n, int n_w, float* __restrict__ dW,
                   float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += partial[(long long)g * n + i];
-  if (i < n_w) dW[i] = s;
-  else if (db) db[i - n_w] = s;
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int g = w;
+    for (; g + 12 < G; g += 16) {
+      s0 += partial[(long long)g * n + i];
+      s1 += partial[(long long)(g + 4) * n + i];
+      s2 += partial[(long long)(g + 8) * n + i];
+      s3 += partial[(long long)(g + 12) * n + i];
+    }
+    for (; g < G; g += 4) s0 += partial[(long long)g * n + i];
+  }
+  float s = (s0 + s1) + (s2 + s3);
+  if (w > 0) red[w - 1][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+    if (i < n_w) dW[i] = s;
+    else if (db) db[i - n_w] = s;
+  }
+}
+
+// Streaming weight gradient on the matrix pipe for big levels (the 20k-vertex level of BASELINE configs[3]:
+// rows = B*N = 1.28 M, stack = 819 MB): dW[kc][c] = sum_rows T[row][kc] * dpre[row][c] is a tall-skinny
+// GEMM whose reduction index is the row, so each wave walks its own contiguous row range four rows at a time
+// and feeds v_mfma_f32_16x16x4_f32 (exact fp32) straight from global memory: lane (m = lane%16, q = lane/16)
+// loads T[row+q][16 t + m] for its M-tiles and dpre[row+q][16 n + m] -- for Cin = 16 every wave load is 256
+// contiguous bytes of one plane.  No LDS staging, no barriers in the loop; the 4 waves of a block are summed
+// through LDS once at the end and the block writes one partial in the layout k_reduce_partials expects
+// ([KC+1][Cout], row KC = db via a ones column).  blockIdx.y selects a group of MT M-tiles (MT*16 stack
+// columns), so the accumulators stay at MT*TN*4 VGPRs; dpre is re-read per group (1/10 of the stack bytes).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int TN, int MT, bool RELU>
+__global__ void __launch_bounds__(256)
+k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ dout,
+               const float* __restrict__ out, float* __restrict__ partial, long long rows, int Cin, int K,
+               long long rows_per_wave) {
+  constexpr int Cout = 16 * TN;
+  __shared__ float red[3][MT * TN][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int KC = K * Cin;
+  const float* ap[MT];
+  float a_load[MT], a_one[MT];  // a = v * a_load + a_one: stack column, ones column (db) or padding
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int kc = ((int)blockIdx.y * MT + t) * 16 + m;
+    ap[t] = x;
+    a_load[t] = 0.f;
+    a_one[t] = 0.f;
+    if (kc < KC) {
+      const int k = kc / Cin, ci = kc - k * Cin;
+      ap[t] = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin) + ci;
+      a_load[t] = 1.f;
+    } else if (kc == KC) {
+      a_one[t] = 1.f;
+    }
+  }
+  f32x4_t acc[MT][TN];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[t][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  const long long r_begin = wid * rows_per_wave;
+  const long long r_end = min(rows, r_begin + rows_per_wave);
+  for (long long r = r_begin; r < r_end; r += 16) {  // 16 rows per trip: four independent load groups in flight
+    float a[4][MT], d[4][TN];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long row_raw = r + 4 * u + q;
+      const float live = row_raw < r_end ? 1.f : 0.f;  // (rows_per_wave is a multiple of 16: only the global tail)
+      const long long row = min(row_raw, rows - 1);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[u][t] = fmaf(ap[t][row * Cin], a_load[t], a_one[t]) * live;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        float v = dout[row * Cout + n * 16 + m] * live;
+        if constexpr (RELU) v = out[row * Cout + n * 16 + m] > 0.f ? v : 0.f;
+        d[u][n] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], d[u][n], acc[t][n], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave - 1][t * TN + n][lane][j] = acc[t][n][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* p = partial + (long long)blockIdx.x * (KC + 1) * Cout;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kc = ((int)blockIdx.y * MT + t) * 16 + 4 * q + j;  // C[m' = 4 q + j][n' = lane % 16]
+          const float v = ((acc[t][n][j] + red[0][t * TN + n][lane][j]) + red[1][t * TN + n][lane][j]) +
+                          red[2][t * TN + n][lane][j];
+          if (kc <= KC) p[(long long)kc * Cout + n * 16 + m] = v;
+        }
+  }
 }
 
 static int dw_grid(long long rows) { return (int)min((long long)512, (rows + kDwRows - 1) / kDwRows); }
@@ -294,19 +466,42 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
                      float* partial, float* dW, float* db, long long rows, int Cin, int Cout, int K,
                      int act) {
   const int KC = K * Cin;
-  const int TI = cdiv(KC + 1, 4), TJ = cdiv(Cout, 4);
-  const int tiles = TI * TJ;
-  const int threads = min(256, cdiv(tiles, 64) * 64);
-  const int gy = cdiv(tiles, threads);
-  const int nchunks = cdiv(rows, kDwRows);
-  const int G = dw_grid(rows);
-  const size_t lds = (size_t)kDwRows * (TI * 4 + TJ * 4) * sizeof(float);
-  if (lds > 64 * 1024) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv dW: K*Cin=%d too large", KC);
-  hipLaunchKernelGGL(k_cheb_dw, dim3(G, gy), dim3(threads), lds, st, x, tx, dout, out, partial, rows, Cin,
-                     Cout, K, act, TI, TJ, nchunks);
-  MVH_LAUNCH_CHECK();
   const int n = (KC + 1) * Cout;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, G, n, KC * Cout,
+  int G = dw_grid(rows);
+  static const char* no_mfma = getenv("MESHVAE_NO_DW_MFMA");
+  if ((Cout == 16 || Cout == 32) && rows >= 4096 && !(no_mfma && no_mfma[0] == '1')) {
+    // big levels: streaming MFMA reduction (k_cheb_dw_mfma); G blocks x 4 waves, contiguous row ranges
+    const long long waves = max(4ll, min(2048ll, rows / 256));
+    G = min(G, (int)((waves + 3) / 4));
+    long long rpw = (rows + (long long)G * 4 - 1) / ((long long)G * 4);
+    rpw = (rpw + 15) / 16 * 16;
+    const int tiles_m = cdiv(KC + 1, 16);
+    const bool relu = act == MVH_ACT_RELU;
+#define MVH_DWM(TN, MT, R)                                                                                          \
+  hipLaunchKernelGGL((k_cheb_dw_mfma<TN, MT, R>), dim3(G, cdiv(tiles_m, MT)), dim3(256), 0, st, x, tx, dout, out, \
+                     partial, rows, Cin, K, rpw)
+    if (Cout == 16) {
+      if (tiles_m <= 2) { if (relu) MVH_DWM(1, 2, true); else MVH_DWM(1, 2, false); }
+      else { if (relu) MVH_DWM(1, 4, true); else MVH_DWM(1, 4, false); }
+    } else {
+      if (tiles_m <= 2) { if (relu) MVH_DWM(2, 2, true); else MVH_DWM(2, 2, false); }
+      else { if (relu) MVH_DWM(2, 4, true); else MVH_DWM(2, 4, false); }
+    }
+#undef MVH_DWM
+    MVH_LAUNCH_CHECK();
+  } else {
+    const int TI = cdiv(KC + 1, 4), TJ = cdiv(Cout, 4);
+    const int tiles = TI * TJ;
+    const int threads = min(256, cdiv(tiles, 64) * 64);
+    const int gy = cdiv(tiles, threads);
+    const int nchunks = cdiv(rows, kDwRows);
+    const size_t lds = (size_t)kDwRows * (TI * 4 + TJ * 4) * sizeof(float);
+    if (lds > 64 * 1024) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv dW: K*Cin=%d too large", KC);
+    hipLaunchKernelGGL(k_cheb_dw, dim3(G, gy), dim3(threads), lds, st, x, tx, dout, out, partial, rows, Cin,
+                       Cout, K, act, TI, TJ, nchunks);
+    MVH_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 64)), dim3(256), 0, st, partial, G, n, KC * Cout,
                      dW, db);
   MVH_LAUNCH_CHECK();
   return MVH_OK;

@@ -19,6 +19,50 @@ struct VecT<4> {
   using type = float4;
 };
 
+// C == 3 (the network input, x y z): one lane owns a whole (mesh, row): the three channels are 12 contiguous
+// bytes, a wave writes 768 contiguous bytes, and the row's col/val words are read once instead of three times
+// (the one-lane-per-channel form took 60 us per propagate at the 20k level for 15 MB of data).
+__global__ void __launch_bounds__(256)
+k_spmm3(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val, int n_rows,
+        int n_cols, const float* __restrict__ x, float* y, const float* add, const float* z, float alpha, float beta,
+        int wg_per_mesh, int xcd_remap) {
+  long long bid = blockIdx.x, b;
+  int tile;
+  if (xcd_remap) {
+    const int xcd = (int)(bid & 7);
+    const long long slot = bid >> 3;
+    b = xcd + 8 * (slot / wg_per_mesh);
+    tile = (int)(slot % wg_per_mesh);
+  } else {
+    b = bid / wg_per_mesh;
+    tile = (int)(bid % wg_per_mesh);
+  }
+  const int r = tile * (int)blockDim.x + (int)threadIdx.x;
+  if (r >= n_rows) return;
+  const float* xb = x + b * (long long)n_cols * 3;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const int e1 = rowptr[r + 1];
+  for (int e = rowptr[r]; e < e1; ++e) {
+    const float* p = xb + (long long)col[e] * 3;
+    const float v = val[e];
+    a0 = fmaf(v, p[0], a0);
+    a1 = fmaf(v, p[1], a1);
+    a2 = fmaf(v, p[2], a2);
+  }
+  const long long o = (b * n_rows + r) * 3;
+  const bool plain = (add == nullptr) && (z == nullptr) && alpha == 1.f;
+  float res[3] = {a0, a1, a2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (!plain) {
+      res[i] = alpha * res[i];
+      if (add) res[i] += add[o + i];
+      if (z) res[i] = fmaf(beta, z[o + i], res[i]);
+    }
+    y[o + i] = res[i];
+  }
+}
+
 template <bool EXACT>
 __device__ __forceinline__ void mac(float& acc, float v, float x) {
   if constexpr (EXACT) {
@@ -34,14 +78,28 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
        int n_rows, int n_cols, const float* __restrict__ x, float* y,
        const float* add, const float* z,  // y may alias add (in-place Clenshaw update)
        float alpha, float beta, int C,
-       long long total) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+       int wg_per_mesh, int xcd_remap) {
+  // One mesh = wg_per_mesh consecutive tiles.  Workgroup ids are dealt round-robin to the 8 XCDs, each with
+  // its own 4 MB L2; with the linear order every XCD touches every mesh and the ~7 gathers per row (a 20k-vertex
+  // level is 1.3 MB per mesh at 16 channels) miss L2 and go to MALL/HBM.  Remapped, XCD x walks the meshes
+  // b = x, x+8, ... one after another, so a mesh's rows stay in that XCD's L2 while its tiles run.
+  long long bid = blockIdx.x;
+  long long b;
+  int tile;
+  if (xcd_remap) {
+    const int xcd = (int)(bid & 7);
+    const long long slot = bid >> 3;
+    b = xcd + 8 * (slot / wg_per_mesh);
+    tile = (int)(slot % wg_per_mesh);
+  } else {
+    b = bid / wg_per_mesh;
+    tile = (int)(bid % wg_per_mesh);
+  }
   const int CV = C / VEC;
-  const int cv = (int)(idx % CV);
-  const long long br = idx / CV;
-  const int r = (int)(br % n_rows);
-  const long long b = br / n_rows;
+  const int in_mesh = tile * (int)blockDim.x + (int)threadIdx.x;
+  if (in_mesh >= n_rows * CV) return;
+  const int cv = in_mesh % CV;
+  const int r = in_mesh / CV;
   const float* xb = x + b * (long long)n_cols * C + (long long)cv * VEC;
   const int e0 = rowptr[r], e1 = rowptr[r + 1];
   float acc[VEC];
@@ -112,11 +170,28 @@ int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, c
                 const float* z, float alpha, float beta, int B, int C, bool exact) {
   if (B == 0 || op->n_rows == 0 || C == 0) return MVH_OK;
   const bool v4 = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)z) % 16 == 0);
-  const long long total = (long long)B * op->n_rows * (v4 ? C / 4 : C);
-  const int grid = cdiv(total, 256);
+  static const char* no_remap3 = getenv("MESHVAE_NO_XCD_REMAP");
+  if (C == 3 && !exact && op->n_rows >= 4096) {  // big level, three channels: one lane per row
+    const int wpm = cdiv(op->n_rows, 256);
+    MVH_REQUIRE((long long)B * wpm < (1ll << 31), "spmm: grid too large");
+    const int remap = (B % 8 == 0 && wpm >= 16 && !(no_remap3 && no_remap3[0] == '1')) ? 1 : 0;
+    hipLaunchKernelGGL(k_spmm3, dim3(B * wpm), dim3(256), 0, st, op->rowptr, op->col, op->val, op->n_rows, op->n_cols,
+                       x, y, add, z, alpha, beta, wpm, remap);
+    MVH_LAUNCH_CHECK();
+    return MVH_OK;
+  }
+  const long long per_mesh = (long long)op->n_rows * (v4 ? C / 4 : C);
+  MVH_REQUIRE(per_mesh < (1ll << 31) - 256, "spmm: level too large");
+  const int wg_per_mesh = (int)cdiv(per_mesh, 256);
+  const long long grid_ll = (long long)B * wg_per_mesh;
+  MVH_REQUIRE(grid_ll < (1ll << 31), "spmm: grid too large");
+  const int grid = (int)grid_ll;
+  static const char* no_remap = getenv("MESHVAE_NO_XCD_REMAP");
+  // (only worth it when one mesh is big enough to thrash: small levels keep the plain order)
+  const int xcd_remap = (B % 8 == 0 && wg_per_mesh >= 16 && !(no_remap && no_remap[0] == '1')) ? 1 : 0;
 #define MVH_SPMM(V, E)                                                                             \
   hipLaunchKernelGGL((k_spmm<V, E>), dim3(grid), dim3(256), 0, st, op->rowptr, op->col, op->val,   \
-                     op->n_rows, op->n_cols, x, y, add, z, alpha, beta, C, total)
+                     op->n_rows, op->n_cols, x, y, add, z, alpha, beta, C, wg_per_mesh, xcd_remap)
   if (v4) {
     if (exact) MVH_SPMM(4, true); else MVH_SPMM(4, false);
   } else {

@@ -29,6 +29,7 @@ struct StepPlan {
   size_t tstack;                         // T_k x of layer 0 at the rows its pooling selects (+ dW partials)
   size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
+  std::vector<size_t> txEnc, txDec;      // saved T_1..T_{K-1} stacks of the levels too big for the LDS kernels
   size_t total;
 };
 
@@ -100,6 +101,15 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   for (int i = 0; i < n; ++i) {  // one byte per vertex and 4 output channels
     if (p.f[i + 1] % 4 == 0) p.encBits[i] = take(cur, ((size_t)B * p.Nn[i] * (p.f[i + 1] / 4) + 3) / 4);
     if (p.f[n - i] % 4 == 0) p.decBits[i] = take(cur, ((size_t)B * p.Nn[n - i - 1] * (p.f[n - i] / 4) + 3) / 4);
+  }
+  // A level beyond the LDS kernels' reach (> 5119 vertices: the 20k level of BASELINE configs[3]) runs the
+  // stack pipeline, whose backward would otherwise rebuild the K-1 propagates of the forward (9 x 80 us at
+  // 16 channels): with 288 GB of HBM the stack (737 MB at B = 64) is simply kept.
+  p.txEnc.assign(n, kNoBits); p.txDec.assign(n, kNoBits);
+  for (int i = 0; i < n; ++i) {
+    if (p.Nn[i] + 1 > 5120 && d->K[i] > 1) p.txEnc[i] = take(cur, (size_t)(d->K[i] - 1) * B * p.Nn[i] * p.f[i]);
+    const int lvl = n - i - 1;
+    if (p.Nn[lvl] + 1 > 5120 && d->K[i] > 1) p.txDec[i] = take(cur, (size_t)(d->K[i] - 1) * B * p.Nn[lvl] * p.f[n + 1 - i]);
   }
   p.scratch_bytes = align_up(scratch, 256);
   p.scratch_main = cur; cur += p.scratch_bytes;
@@ -182,6 +192,7 @@ extern "C" int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc) {
 
 #define F(off) ((float*)((char*)ws + (off)))
 #define BITS(off) ((off) == kNoBits ? (uint8_t*)nullptr : (uint8_t*)((char*)ws + (off)))
+#define TX(off) ((off) == kNoBits ? (float*)nullptr : (float*)((char*)ws + (off)))
 #define TRY(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
 
 extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
@@ -231,7 +242,7 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   const float* cur = x;
   for (int i = 0; i < n; ++i) {
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
-    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), nullptr, B,
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), TX(p.txEnc[i]), B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
                            &d->down[i], F(p.encP[i]), BITS(p.encBits[i])));
     cur = F(p.encP[i]);
@@ -250,7 +261,7 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
-                           nullptr, B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i]),
+                           TX(p.txDec[i]), B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i]),
                            more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr, BITS(p.decBits[i])));
     cur = F(p.decC[i]);
   }
@@ -314,6 +325,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     size_t part_off, part_bytes;
     const mvh_csr_t *dout_pool, *unpool_t;  // dout is the gradient of the POOLED output (fused un-pooling);
     float* unpooled;                        // fallback: un-pool with unpool_t into this buffer first
+    const float* tx;                        // T_k stack kept by the forward (big levels), else null
   };
   PendingDw pending[4];
   int n_pending = 0;
@@ -336,7 +348,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
       const float* dout = w.dout;
       if (w.dout_pool) {
-        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, nullptr, nullptr, w.dW, w.db, B, w.N,
+        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, w.tx, nullptr, w.dW, w.db, B, w.N,
                                w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, w.dout_pool, &fused, w.bits,
                                nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
                                &deferred));
@@ -346,7 +358,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
         }
       }
       if (!fused)
-        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, nullptr, nullptr, w.dW, w.db, B, w.N,
+        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, w.tx, nullptr, w.dW, w.db, B, w.N,
                                w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
                                can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred));
       if (deferred) ++red.n;
@@ -358,9 +370,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                           const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
                           int K, int act, const uint8_t* bits, size_t part_off = kNoBits, size_t part_bytes = 0,
                           const mvh_csr_t* dout_pool = nullptr, const mvh_csr_t* unpool_t = nullptr,
-                          float* unpooled = nullptr) -> int {
+                          float* unpooled = nullptr, const float* tx = nullptr) -> int {
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
-                                     dout_pool, unpool_t, unpooled};
+                                     dout_pool, unpool_t, unpooled, tx};
     if (n_pending >= fork_batch) return flush_dw(false);
     return MVH_OK;
   };
@@ -390,7 +402,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]),
-                     p.dwPartDec[i], p.dwPartBytesDec[i]));
+                     p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, TX(p.txDec[i])));
     if (i == n - 1 && use_tstack) {
       // T_k x of encoder layer 0 at its pooled rows: 64 workgroups on the side lane behind the (chip-filling)
       // dW above, i.e. while the main chain runs its small-level kernels; consumed at the very end
@@ -454,7 +466,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
-                       p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i])));
+                       p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i]), TX(p.txEnc[i])));
       bool ok_dx = false;
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
@@ -497,13 +509,13 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       continue;
     }
     bool ok_dw = false, deferred = false;
-    TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]), nullptr,
+    TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]), TX(p.txEnc[0]),
                            nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
                            p.scratch_bytes, nullptr, &d->down[0], &ok_dw, BITS(p.encBits[0]), nullptr, &red.e[red.n],
                            F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred));
     if (!ok_dw) {
       TRY(mvh_pool_bwd(stream, &d->down_t[0], F(p.g_encP[0]), F(p.g_encA[0]), B, p.f[1]));
-      TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encA[0]), nullptr,
+      TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encA[0]), TX(p.txEnc[0]),
                              nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
                              p.scratch_bytes, nullptr, nullptr, nullptr, BITS(p.encBits[0]), nullptr, &red.e[red.n],
                              F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred));

@@ -259,3 +259,44 @@ def test_dense_gradients_are_final_at_the_library_event():
     t.start()
     t.join()
     assert err and "no mvh_vae_backward" in err[0]
+
+
+def test_native_step_hires_20k_equals_module_path():
+    """BASELINE configs[3] through the native step: level 0 (19 992 vertices) runs the stack pipeline, whose
+    T_k stacks the native forward keeps for the backward (the module path rebuilds them) and whose weight
+    gradients / G stacks run on the matrix pipe -- same kernels either way, so the two paths must agree."""
+    from conftest import CFG_20K
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_20k.npz"), dev)
+    B = 3
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, nn_[0], 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+
+    class D_:
+        pass
+
+    d = D_()
+    d.x, d.num_graphs, d.edge_index = x.reshape(-1, 3), B, None
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(666)
+        nets.append(cheb_VAE(3, dict(CFG_20K, dropout=0.0), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train())
+    a, b = nets
+    a._eps_provider = lambda B_, Z_, dev_: eps
+    loss_a, _, recon_a, _, _ = a(d, x.double(), y, m_type="train")
+    loss_a.backward()
+    loss_b, _, recon_b, _, _ = NativeStep(b, B).forward_backward(x, x.double(), y, eps=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(recon_a.detach(), recon_b)
+    torch.testing.assert_close(loss_b, loss_a.detach(), rtol=1e-12, atol=0)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert float(pb.grad.abs().sum()) == 0.0, k
+        else:
+            err = float((pa.grad - pb.grad).norm()) / max(float(pa.grad.norm()), 1e-20)
+            assert err < 1e-6, (k, err)

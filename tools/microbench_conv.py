@@ -17,6 +17,7 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--topology", default="topology_5k.npz", help="hierarchy fixture under tests/golden")
     ap.add_argument("--level", type=int, default=0)
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
@@ -33,7 +34,7 @@ def main():
     from meshvae_hip.functional import workspace
     from nn.conv import ChebConv_batch
     dev = torch.device("cuda:0")
-    z = np.load(os.path.join(ROOT, "tests", "golden", "topology_5k.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", args.topology))
     N = int(z["num_nodes"][args.level])
     ei = torch.from_numpy(np.vstack([z[f"A{args.level}_row"], z[f"A{args.level}_col"]]).astype(np.int64)).to(dev)
     ei, nrm = ChebConv_batch.norm(ei, N)
