@@ -16,10 +16,13 @@ aligned dataset lives in HBM (1076 meshes x 4998 x 3 doubles = 129 MB of 288 GB)
 
 MI355X only: there is no CPU fallback (the oracle's restatement is test infrastructure).
 """
+import os
+
 import numpy as np
 import torch
 from scipy.linalg import svd as _svd
 
+import mesh_operations
 from meshvae_hip import check, lib
 
 
@@ -86,6 +89,38 @@ def procrustes(data1, data2, device="cuda:0"):
             [r["R"][0].cpu().numpy(), float(r["s"][0]), r["m"][0].cpu().numpy()])
 
 
+def list_meshes(config, get_sex_from_file_name=True):
+    """(dataset_index, labels) of the .obj files under config['root_dir'] (reference data.py:40-72): sorted names,
+    minus the names listed in config['error_file'], label 0 for `<id>_f_...`, 1 otherwise (-1 when not parsed)."""
+    labels, dataset_index, to_remove = {}, [], {}
+    error_file = config.get("error_file", "")
+    if len(error_file) > 0:
+        with open(error_file) as f:
+            for line in f.read().split("\n"):
+                to_remove[line.split(" ")[0]] = True
+    n_meshes = n_rejected = 0
+    for name in sorted(os.listdir(config["root_dir"])):
+        if not name.endswith(".obj"):
+            continue
+        n_meshes += 1
+        if name.split("/").pop() in to_remove:
+            n_rejected += 1
+            continue
+        dataset_index.append(name)
+        labels[name] = (0 if name.split("_")[1] == "f" else 1) if get_sex_from_file_name else -1
+    print("Dataset : {} meshes, {} rejected meshes, {} remaining meshes".format(n_meshes, n_rejected, len(dataset_index)))
+    return dataset_index, labels
+
+
+def save_obj(filename, vertices, faces):
+    """`v x y z` / 1-based `f a b c` records (reference data.py:20-27)."""
+    with open(filename, "w") as fp:
+        for v in vertices:
+            fp.write("v %f %f %f\n" % (v[0], v[1], v[2]))
+        for f in np.asarray(faces) + 1:
+            fp.write("f %d %d %d\n" % (f[0], f[1], f[2]))
+
+
 class DeviceDataset:
     """MeshData (data.py:75-200) with everything resident on the device.
 
@@ -108,6 +143,26 @@ class DeviceDataset:
         else:
             mean, std = (torch.as_tensor(np.asarray(t), dtype=torch.float64).to(device) for t in norm)
         self.mean, self.std = mean.contiguous(), std.contiguous()
+
+    @classmethod
+    def from_directory(cls, dataset_index, config, labels, template, dtype="train", device="cuda:0"):
+        """MeshData(dataset_index, config, label, template, dtype) (reference data.py:84-200): reads
+        config['root_dir']/<name> for every name that exists, aligns, and handles norm.npz the way the reference does
+        (data.py:166-184): a 'train' split writes config['checkpoint_dir']/norm.npz if it is not there yet, every
+        split then normalises with the file's statistics."""
+        names = [n for n in dataset_index if os.path.exists(os.path.join(config["root_dir"], n))]
+        meshes = np.stack([mesh_operations.read_obj(os.path.join(config["root_dir"], n))[0] for n in names])
+        ds = cls(meshes, [labels[n] for n in names], template, norm=None, device=device)
+        ds.filename = [os.path.join(config["root_dir"], n) for n in names]
+        norm_file = os.path.join(config["checkpoint_dir"], "norm.npz")
+        if not os.path.exists(norm_file) and dtype == "train":
+            os.makedirs(config["checkpoint_dir"], exist_ok=True)
+            np.savez(os.path.join(config["checkpoint_dir"], "norm"), mean=ds.mean.cpu().numpy(), std=ds.std.cpu().numpy())
+        stats = np.load(norm_file, allow_pickle=True)
+        ds.mean = torch.as_tensor(stats["mean"], dtype=torch.float64).to(ds.device).contiguous()
+        ds.std = torch.as_tensor(stats["std"], dtype=torch.float64).to(ds.device).contiguous()
+        print(dtype, " dataset has been created, number of {} samples:".format(dtype), len(ds))
+        return ds
 
     def __len__(self):
         return self.ori_data.shape[0]

@@ -222,3 +222,24 @@ def test_flat_buffer_splits_into_conv_head_and_dense_tail():
     assert flat.names[k] == "classifier_layer.weight" and flat.names[k - 1].startswith("cheb_dec.")
     assert split % FlatParams.ALIGN == 0 and 0 < split < flat.numel
     assert FlatParams(torch.nn.Linear(3, 4)).conv_dense_split() is None        # no conv head: no split
+
+
+def test_list_meshes_and_obj_round_trip(tmp_path, capsys):
+    """preprocess.list_meshes mirrors data.py:40-72 (sorted .obj names, error-file filter, sex from the file name)."""
+    from mesh_operations import read_obj
+    from preprocess import list_meshes, save_obj
+    v = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.5, 0.0], [0.25, 0.25, 2.0]])
+    f = np.array([[0, 1, 2], [0, 1, 3]])
+    for name in ("0002_m_0.obj", "0001_f_0.obj", "0003_f_1.obj", "notes.txt"):
+        if name.endswith(".obj"):
+            save_obj(str(tmp_path / name), v, f)
+        else:
+            (tmp_path / name).write_text("x")
+    (tmp_path / "bad.lst").write_text("0003_f_1.obj some reason\n")
+    index, labels = list_meshes({"root_dir": str(tmp_path), "error_file": str(tmp_path / "bad.lst")})
+    assert index == ["0001_f_0.obj", "0002_m_0.obj"] and labels == {"0001_f_0.obj": 0, "0002_m_0.obj": 1}
+    assert "3 meshes, 1 rejected meshes, 2 remaining meshes" in capsys.readouterr().out
+    index, labels = list_meshes({"root_dir": str(tmp_path), "error_file": ""}, get_sex_from_file_name=False)
+    assert len(index) == 3 and set(labels.values()) == {-1}
+    v2, f2 = read_obj(str(tmp_path / "0001_f_0.obj"))
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)
