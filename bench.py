@@ -183,6 +183,12 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (rank 0's JSON): libraries that print there (RCCL writes a five-line version
+    # banner to stdout when the first communicator comes up) are pointed at stderr until that line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -267,7 +273,8 @@ def main():
             out["kernels"] = {k: {"avg_ms": v["ms"], "algo_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, 8)   # ~10-20 s of CPU work on 16 cores
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
