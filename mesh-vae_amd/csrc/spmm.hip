@@ -102,6 +102,23 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
   const int r = in_mesh / CV;
   const float* xb = x + b * (long long)n_cols * C + (long long)cv * VEC;
   const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  // the recurrence's T_{k-2} term is the one stream of this kernel that comes from HBM rather than L2: issue its
+  // load first so that it is in flight underneath the gathers
+  const long long o_pre = (b * n_rows + r) * (long long)C + (long long)cv * VEC;
+  float zpre[VEC];
+  if constexpr (VEC == 4) {
+    const float4 t = z ? *reinterpret_cast<const float4*>(z + o_pre) : make_float4(0.f, 0.f, 0.f, 0.f);
+    zpre[0] = t.x; zpre[1] = t.y; zpre[2] = t.z; zpre[3] = t.w;
+  } else {
+    zpre[0] = z ? z[o_pre] : 0.f;
+  }
+  float apre[VEC];  // (same for the additive term: G_k of the Clenshaw update; y may alias it, it is read before the store)
+  if constexpr (VEC == 4) {
+    const float4 t = add ? *reinterpret_cast<const float4*>(add + o_pre) : make_float4(0.f, 0.f, 0.f, 0.f);
+    apre[0] = t.x; apre[1] = t.y; apre[2] = t.z; apre[3] = t.w;
+  } else {
+    apre[0] = add ? add[o_pre] : 0.f;
+  }
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -154,8 +171,8 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
     float res = acc[i];
     if (!plain) {
       res = alpha * res;
-      if (add) res += add[o + i];
-      if (z) res = fmaf(beta, z[o + i], res);
+      if (add) res += apre[i];
+      if (z) res = fmaf(beta, zpre[i], res);
     }
     acc[i] = res;
   }
