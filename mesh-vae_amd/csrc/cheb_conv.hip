@@ -25,6 +25,36 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
   float acc[COUT_T];
 #pragma unroll
   for (int co = 0; co < COUT_T; ++co) acc[co] = (bias && (FULL || co < Cout)) ? bias[co] : 0.f;
+  if constexpr (VIN && FULL && COUT_T == 16) {
+    if (Cin == 16) {  // the stack planes are the kernel's HBM stream: plane k+1 is in flight while plane k is used
+      float4 cur[4], nxt[4];
+      {
+        const float4* s0 = reinterpret_cast<const float4*>(x + r * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = s0[j];
+      }
+      for (int k = 0; k < K; ++k) {
+        const int kn = min(k + 1, K - 1);  // (the last trip re-reads its own plane: no branch around the loads)
+        const float4* sn = reinterpret_cast<const float4*>((kn == 0 ? x : tx + (long long)(kn - 1) * rows * 16) + r * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt[j] = sn[j];
+        const float* Wk = W + (long long)k * 16 * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float tv[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float* w = Wk + (j * 4 + t) * 16;
+#pragma unroll
+            for (int co = 0; co < 16; ++co) acc[co] = fmaf(tv[t], w[co], acc[co]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+      }
+      K = 0;  // done: skip the generic loop below
+    }
+  }
   for (int k = 0; k < K; ++k) {
     const float* src = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin) + r * Cin;
     const float* Wk = W + (long long)k * Cin * Cout;
