@@ -510,9 +510,10 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
 #define MVH_DWM(TN, MT, R)                                                                                          \
   hipLaunchKernelGGL((k_cheb_dw_mfma<TN, MT, R>), dim3(G, cdiv(tiles_m, MT)), dim3(256), 0, st, x, tx, dout, out, \
                      partial, rows, Cin, K, rpw)
-    if (Cout == 16) {
+    if (Cout == 16) {  // (MT = 6: two passes over dpre instead of three for 11 M-tiles; all 11 at once was slower)
       if (tiles_m <= 2) { if (relu) MVH_DWM(1, 2, true); else MVH_DWM(1, 2, false); }
-      else { if (relu) MVH_DWM(1, 4, true); else MVH_DWM(1, 4, false); }
+      else if (tiles_m <= 4 || tiles_m > 12) { if (relu) MVH_DWM(1, 4, true); else MVH_DWM(1, 4, false); }
+      else { if (relu) MVH_DWM(1, 6, true); else MVH_DWM(1, 6, false); }
     } else {
       if (tiles_m <= 2) { if (relu) MVH_DWM(2, 2, true); else MVH_DWM(2, 2, false); }
       else { if (relu) MVH_DWM(2, 4, true); else MVH_DWM(2, 4, false); }
