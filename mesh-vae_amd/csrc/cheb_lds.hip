@@ -234,18 +234,41 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   // acc[vi] += xs[vi][:] . W_k[:, slab]   (weights are wave-uniform: scalar loads, SGPR operands)
   const bool slab_full = s0 + 4 <= a.CO;
   const float* __restrict__ wslab = p_W + (long long)(s0 >> 2) * a.K * CQ * 4;
+  // On the matrix pipe: v_mfma_f32_4x4x1 (16 independent 4x4 outer products, K = 1) with A = W_k[c][0..3]
+  // replicated in every block (lane l supplies W_k[c][l & 3]) and B = the lane's own x[c]: block b's result
+  // column j -- the four output channels of the vertex of lane 4 b + j -- lands in that very lane's accumulator,
+  // i.e. the thread-per-vertex layout needs no shuffles.  One instruction does the work of four v_fma on a pipe
+  // that runs beside the VALU, and the weights arrive as ONE round of CQ vector loads per order (4 distinct
+  // addresses per wave) instead of up to 7 dependent scalar-load rounds when CQ * 4 exceeds the SGPR file.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const float* __restrict__ wlane = wslab + (tid & 3);
+  // (Small levels only: at the 5k level the CQ extra VGPRs of the weight column spill in the 1024 x 5 shape
+  //  -- 49.8 vs 42.7 us -- so those variants keep the scalar-operand v_fma form.)
   auto contract = [&](float4(&acc)[VPT], int k) {
+    if constexpr (TCT == 0) {
+      float wv[CQ];
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) {
-      // p_W is the slab-packed copy [slab][k][c][4] (k_pack_w): contiguous, so one order's
-      // weights arrive in a few wide s_load instead of CQ*4 dependent scalar loads
-      const float* w = wslab + (k * CQ + c) * 4;
+      for (int c = 0; c < CQ; ++c) wv[c] = wlane[(k * CQ + c) * 4];
 #pragma unroll
       for (int vi = 0; vi < VPT; ++vi) {
-        acc[vi].x = fmaf(xs[vi][c], w[0], acc[vi].x);
-        acc[vi].y = fmaf(xs[vi][c], w[1], acc[vi].y);
-        acc[vi].z = fmaf(xs[vi][c], w[2], acc[vi].z);
-        acc[vi].w = fmaf(xs[vi][c], w[3], acc[vi].w);
+        v4f t = {acc[vi].x, acc[vi].y, acc[vi].z, acc[vi].w};
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) t = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[c], xs[vi][c], t, 0, 0, 0);
+        acc[vi] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        // p_W is the slab-packed copy [slab][k][c][4] (k_pack_w): contiguous, so one order's
+        // weights arrive in a few wide s_load instead of CQ*4 dependent scalar loads
+        const float* w = wslab + (k * CQ + c) * 4;
+#pragma unroll
+        for (int vi = 0; vi < VPT; ++vi) {
+          acc[vi].x = fmaf(xs[vi][c], w[0], acc[vi].x);
+          acc[vi].y = fmaf(xs[vi][c], w[1], acc[vi].y);
+          acc[vi].z = fmaf(xs[vi][c], w[2], acc[vi].z);
+          acc[vi].w = fmaf(xs[vi][c], w[3], acc[vi].w);
+        }
       }
     }
   };
