@@ -244,11 +244,17 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   const float* __restrict__ wlane = wslab + (tid & 3);
   // (Small levels only: at the 5k level the CQ extra VGPRs of the weight column spill in the 1024 x 5 shape
   //  -- 49.8 vs 42.7 us -- so those variants keep the scalar-operand v_fma form.)
-  auto contract = [&](float4(&acc)[VPT], int k) {
+  // The weight column of the NEXT order is fetched right after the current one has been used, so its latency sits
+  // under the gathers / the barrier instead of in front of the matrix instructions.
+  float wv[TCT == 0 ? CQ : 1];
+  auto load_w = [&](int k) {
     if constexpr (TCT == 0) {
-      float wv[CQ];
 #pragma unroll
       for (int c = 0; c < CQ; ++c) wv[c] = wlane[(k * CQ + c) * 4];
+    }
+  };
+  auto contract = [&](float4(&acc)[VPT], int k) {
+    if constexpr (TCT == 0) {
 #pragma unroll
       for (int vi = 0; vi < VPT; ++vi) {
         v4f t = {acc[vi].x, acc[vi].y, acc[vi].z, acc[vi].w};
@@ -256,6 +262,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
         for (int c = 0; c < CQ; ++c) t = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[c], xs[vi][c], t, 0, 0, 0);
         acc[vi] = make_float4(t[0], t[1], t[2], t[3]);
       }
+      if (k > 0) load_w(k - 1);
     } else {
 #pragma unroll
       for (int c = 0; c < CQ; ++c) {
@@ -321,6 +328,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   };
 
   float4* stage = slab;  // where a fused pooling parks the result rows
+  load_w(a.K - 1);
   if (a.K >= 2) {
     contract(R, a.K - 1);
 #pragma unroll
