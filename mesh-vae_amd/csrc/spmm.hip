@@ -40,6 +40,10 @@ k_spmm3(const int* __restrict__ rowptr, const int* __restrict__ col, const float
   const int r = tile * (int)blockDim.x + (int)threadIdx.x;
   if (r >= n_rows) return;
   const float* xb = x + b * (long long)n_cols * 3;
+  const long long o = (b * n_rows + r) * 3;
+  float zp[3] = {0.f, 0.f, 0.f}, ap[3] = {0.f, 0.f, 0.f};  // the HBM-resident terms first (see k_spmm)
+  if (z) { zp[0] = z[o]; zp[1] = z[o + 1]; zp[2] = z[o + 2]; }
+  if (add) { ap[0] = add[o]; ap[1] = add[o + 1]; ap[2] = add[o + 2]; }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   const int e1 = rowptr[r + 1];
   for (int e = rowptr[r]; e < e1; ++e) {
@@ -49,15 +53,14 @@ k_spmm3(const int* __restrict__ rowptr, const int* __restrict__ col, const float
     a1 = fmaf(v, p[1], a1);
     a2 = fmaf(v, p[2], a2);
   }
-  const long long o = (b * n_rows + r) * 3;
   const bool plain = (add == nullptr) && (z == nullptr) && alpha == 1.f;
   float res[3] = {a0, a1, a2};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (!plain) {
       res[i] = alpha * res[i];
-      if (add) res[i] += add[o + i];
-      if (z) res[i] = fmaf(beta, z[o + i], res[i]);
+      if (add) res[i] += ap[i];
+      if (z) res[i] = fmaf(beta, zp[i], res[i]);
     }
     y[o + i] = res[i];
   }
