@@ -8,6 +8,7 @@ per step, followed by the 1/world scale folded into the optimizer kernel.  Param
 gradients live in two contiguous buffers so no bucketing copies exist; `dec_lin_1` (never
 used, cheb_VAE.py:165) stays in the buffers with a zero gradient.
 """
+import ctypes
 import os
 
 import torch
@@ -420,9 +421,10 @@ class NativeStep:
         L = lib()
         self.params = [p for _, p in net.named_parameters()]
         assert len(self.params) == L.mvh_vae_param_count(ctypes.byref(d)), "unexpected parameter list"
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+        if grads is None:                    # default: gradients land in the parameters' own .grad tensors
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
         PtrArr = ctypes.c_void_p * len(self.params)
         self._P = PtrArr(*[p.data_ptr() for p in self.params])
         self.grads = grads if grads is not None else [p.grad for p in self.params]
@@ -440,6 +442,20 @@ class NativeStep:
         self._loss = {}
         from models.cheb_VAE import LOG_SIGMA
         self.log_sigma = LOG_SIGMA
+
+    def backward(self, x, x_gt, y_f, d_loss, eps=None, drop_u=None):
+        """loss.backward() for the forward this object ran last (activations live in its workspace): the gradient
+        of every parameter times the scalar `d_loss` (a 0-d device tensor of the loss dtype) goes to `self.grads`."""
+        L = lib()
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        f64 = int(x_gt.dtype == torch.float64)
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            check(L.mvh_vae_backward(st, ctypes.byref(self.desc), self._P, self._G, x.data_ptr(), y_f.data_ptr(),
+                                     x_gt.data_ptr(), f64, ptr(eps), ptr(drop_u), self.B, self.log_sigma,
+                                     d_loss.data_ptr(), self.recon.data_ptr(), self.y_hat.data_ptr(), self.mu.data_ptr(),
+                                     self.logvar.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                     self.side.cuda_stream if self.side is not None else None))
 
     def _refresh_pointers(self):
         for i, p in enumerate(self.params):

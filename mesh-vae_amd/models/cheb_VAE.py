@@ -29,6 +29,40 @@ from nn.pool import SurfacePool
 LOG_SIGMA = float(torch.nn.functional.softplus(torch.tensor([7.0])) - 6.0)
 
 
+class _FusedModelFn(torch.autograd.Function):
+    """cheb_VAE.forward as one autograd node (see cheb_VAE._forward_fused).  Only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, ent, x, x_gt, y, eps, drop_u, *params):
+        step = ent["step"]
+        loss, correct, recon, (kld, rec, z_), y_hat = step.forward_backward(x, x_gt, y, eps=eps, drop_u=drop_u,
+                                                                             backward=False)
+        y_f = y if (y.dtype == torch.float32 and y.is_contiguous()) else step.y_f.clone()
+        ctx.ent, ctx.gen = ent, ent["gen"]
+        ctx.saved = (x, x_gt, y_f, eps, drop_u)
+        outs = (loss.clone(), correct.clone(), recon.clone(), kld.clone(), rec.clone(), z_.clone(), y_hat.clone())
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_loss, *_):
+        ent = ctx.ent
+        if ent["gen"] != ctx.gen:
+            raise RuntimeError("cheb_VAE fused forward: backward() must follow its own forward (the activations of an "
+                               "earlier forward of this batch size were overwritten); set net.fused_step = False "
+                               "to keep several graphs alive")
+        x, x_gt, y_f, eps, drop_u = ctx.saved
+        step = ent["step"]
+        step.backward(x, x_gt, y_f, d_loss.contiguous(), eps=eps, drop_u=drop_u)
+        flat = ent["flat"].clone()                      # autograd may keep / accumulate into what it is handed
+        grads, off = [], 0
+        for name, p in zip(step.net._fused_names(), step.params):
+            g = flat[off:off + p.numel()].view_as(p)
+            off += -(-p.numel() // 64) * 64
+            grads.append(None if name.startswith("dec_lin_1.") else g)   # never used by the forward (reference :165)
+        return (None, None, None, None, None, None, *grads)
+
+
 class cheb_VAE(torch.nn.Module):
 
     def __init__(self, num_features, config, downsample_matrices, upsample_matrices,
@@ -80,6 +114,9 @@ class cheb_VAE(torch.nn.Module):
         self._down = [topology.pool_operator(m) for m in self.downsample_matrices]
         self._up = [topology.pool_operator(m) for m in self.upsample_matrices]
         self._ops_ready = True
+
+    def _fused_names(self):
+        return [n for n, _ in self.named_parameters()]
 
     def reset_parameters(self):
         nn.init.normal_(self.enc_lin.weight, 0, 0.1)
@@ -153,10 +190,46 @@ class cheb_VAE(torch.nn.Module):
         return F_hip.vae_loss(recon_x, x, mu_z, logvar_z, y.to(torch.float32), y_hat, LOG_SIGMA)
 
     # ------------------------------------------------------------------ full step
+    def _forward_fused(self, x, x_gt, y, m_type):
+        """The whole forward as ONE autograd node over the native step (mvh_vae_forward / mvh_vae_backward):
+        what `loss.backward()` in the reference's train loop (main.py:80) then triggers is a single C++ launch
+        sequence instead of ~60 Python-driven autograd nodes -- bitwise the same numbers (same kernels)."""
+        from meshvae_hip.engine import NativeStep
+        B, dev = x.shape[0], x.device
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        ent = cache.get(B)
+        if ent is None:
+            if len(cache) >= 3:                      # (a workspace is ~12 MB per mesh: keep few batch sizes)
+                cache.pop(next(iter(cache)))
+            params = [p for _, p in self.named_parameters()]
+            flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in params), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += -(-p.numel() // 64) * 64
+            ent = cache[B] = {"step": NativeStep(self, B, grads=views), "flat": flat, "views": views, "gen": 0}
+        step = ent["step"]
+        step._refresh_pointers()
+        eps = None
+        if m_type == "train":
+            provider = getattr(self, "_eps_provider", None)
+            eps = provider(B, self.z, dev) if provider is not None else \
+                torch.normal(mean=0, std=1, size=(B, self.z)).to(dev)      # host generator, as the reference (:316)
+        drop_u = torch.rand(B * step.u_cols, device=dev) if (self.training and self.dropout.p > 0.0) else None
+        ent["gen"] += 1
+        outs = _FusedModelFn.apply(ent, x.contiguous(), x_gt.contiguous(), y, eps, drop_u, *step.params)
+        loss, correct, recon, kld, rec, z_, y_hat = outs
+        return loss, correct, recon, [kld, rec, z_], y_hat
+
     def forward(self, data, x_gt, y, supervise=True, m_type="test"):
         self.supervise = supervise
         x, batch_size = data.x, data.num_graphs          # data.edge_index is never used (reference :195)
         x = x.reshape(batch_size, -1, self.filters[0])
+        if (getattr(self, "fused_step", True) and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
+                and not x_gt.requires_grad and x_gt.dtype in (torch.float32, torch.float64)
+                and all(p.requires_grad for p in self.parameters())):
+            self._prepare()
+            return self._forward_fused(x, x_gt, y, m_type)
         h = self.encoder(x)
         y_hat, x_mean, x_var, z_, z = self._latent(h, y, m_type)
         x = self.decoder(z).reshape(batch_size, -1, self.filters[0])

@@ -139,6 +139,7 @@ def test_native_step_equals_module_path(gt_dtype):
     d = D()
     d.x, d.num_graphs, d.edge_index = x.reshape(-1, 3), B, None
     a, b = _net(dev), _net(dev)
+    a.fused_step = False                                      # the per-module autograd path
     a.train(), b.train()                                      # dropout p = 0: deterministic
     a._eps_provider = lambda B_, Z_, dev_: eps
     loss_a, corr_a, recon_a, (kld_a, rec_a, z_a), yh_a = a(d, x.to(gt_dtype), y, m_type="train")
@@ -181,6 +182,7 @@ def test_native_step_unusual_configs_match_module_path(cfg_over, B):
         torch.manual_seed(11)
         nets.append(cheb_VAE(3, cfg, D, U, A, nn_).to(dev).train())
     a, b = nets
+    a.fused_step = False                                      # the per-module autograd path
     x = torch.randn(B, 162, 3, generator=torch.Generator().manual_seed(4)).to(dev)
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
     eps = torch.randn(B, 16, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -287,6 +289,7 @@ def test_native_step_hires_20k_equals_module_path():
         torch.manual_seed(666)
         nets.append(cheb_VAE(3, dict(CFG_20K, dropout=0.0), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train())
     a, b = nets
+    a.fused_step = False                                      # the per-module autograd path
     a._eps_provider = lambda B_, Z_, dev_: eps
     loss_a, _, recon_a, _, _ = a(d, x.double(), y, m_type="train")
     loss_a.backward()
@@ -300,3 +303,54 @@ def test_native_step_hires_20k_equals_module_path():
         else:
             err = float((pa.grad - pb.grad).norm()) / max(float(pa.grad.norm()), 1e-20)
             assert err < 1e-6, (k, err)
+
+
+def test_module_forward_is_one_fused_autograd_node():
+    """cheb_VAE.forward under grad mode runs the native step behind a single autograd node (what main.py's
+    `loss.backward()` then triggers): same numbers as the per-module path, gradients ACCUMULATE like any autograd
+    result, dec_lin_1 keeps grad None, and a backward through stale activations is refused."""
+    dev = torch.device("cuda:0")
+    B = 5
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 162, 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+
+    class D:
+        pass
+
+    d = D()
+    d.x, d.num_graphs, d.edge_index = x.reshape(-1, 3), B, None
+    a, b = _net(dev), _net(dev)
+    a.fused_step = False
+    for n_ in (a, b):
+        n_.train()
+        n_._eps_provider = lambda B_, Z_, dev_: eps
+    out_a = a(d, x.double(), y, m_type="train")
+    out_b = b(d, x.double(), y, m_type="train")
+    assert out_b[0].grad_fn is not None and type(out_b[0].grad_fn).__name__.startswith("_FusedModelFn")
+    assert not out_b[2].requires_grad and out_b[0].dtype == torch.float64
+    for u, v in zip((out_a[0], out_a[2], out_a[3][0], out_a[3][1], out_a[3][2], out_a[4]),
+                    (out_b[0], out_b[2], out_b[3][0], out_b[3][1], out_b[3][2], out_b[4])):
+        assert torch.equal(u.detach(), v.detach())
+    assert int(out_a[1]) == int(out_b[1])
+    (out_a[0] * 0.5).backward()
+    (out_b[0] * 0.5).backward()                               # an upstream factor reaches every gradient
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None, k                         # dec_lin_1
+        else:
+            torch.testing.assert_close(pb.grad, pa.grad, rtol=1e-6, atol=1e-7, msg=k)
+    first = {k: p.grad.clone() for k, p in b.named_parameters() if p.grad is not None}
+    b(d, x.double(), y, m_type="train")[0].backward()         # no zero_grad in between: 0.5 g + g
+    for k, p in b.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(p.grad, 3.0 * first[k], rtol=1e-5, atol=1e-6, msg=k)
+    stale = b(d, x.double(), y, m_type="train")[0]
+    b(d, x.double(), y, m_type="train")
+    with pytest.raises(RuntimeError, match="must follow its own forward"):
+        stale.backward()
+    # no grad mode / eval: the per-module path, nothing fused
+    b.eval()
+    with torch.no_grad():
+        assert b(d, x, y, m_type="test")[0].grad_fn is None
