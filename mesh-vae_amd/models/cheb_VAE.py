@@ -217,6 +217,10 @@ class cheb_VAE(torch.nn.Module):
                 torch.normal(mean=0, std=1, size=(B, self.z)).to(dev)      # host generator, as the reference (:316)
         drop_u = torch.rand(B * step.u_cols, device=dev) if (self.training and self.dropout.p > 0.0) else None
         ent["gen"] += 1
+        if not torch.is_grad_enabled():              # evaluate loops (main.py:129): the same launch sequence, forward only
+            loss, correct, recon, (kld, rec, z_), y_hat = step.forward_backward(x.contiguous(), x_gt.contiguous(), y,
+                                                                                 eps=eps, drop_u=drop_u, backward=False)
+            return loss.clone(), correct.clone(), recon.clone(), [kld.clone(), rec.clone(), z_.clone()], y_hat.clone()
         outs = _FusedModelFn.apply(ent, x.contiguous(), x_gt.contiguous(), y, eps, drop_u, *step.params)
         loss, correct, recon, kld, rec, z_, y_hat = outs
         return loss, correct, recon, [kld, rec, z_], y_hat
@@ -225,9 +229,10 @@ class cheb_VAE(torch.nn.Module):
         self.supervise = supervise
         x, batch_size = data.x, data.num_graphs          # data.edge_index is never used (reference :195)
         x = x.reshape(batch_size, -1, self.filters[0])
-        if (getattr(self, "fused_step", True) and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
-                and not x_gt.requires_grad and x_gt.dtype in (torch.float32, torch.float64)
-                and all(p.requires_grad for p in self.parameters())):
+        no_grad = not torch.is_grad_enabled()
+        if (getattr(self, "fused_step", True) and x.is_cuda and x_gt.dtype in (torch.float32, torch.float64)
+                and (no_grad or (not x.requires_grad and not x_gt.requires_grad
+                                 and all(p.requires_grad for p in self.parameters())))):
             self._prepare()
             return self._forward_fused(x, x_gt, y, m_type)
         h = self.encoder(x)

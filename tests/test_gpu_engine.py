@@ -350,7 +350,11 @@ def test_module_forward_is_one_fused_autograd_node():
     b(d, x.double(), y, m_type="train")
     with pytest.raises(RuntimeError, match="must follow its own forward"):
         stale.backward()
-    # no grad mode / eval: the per-module path, nothing fused
-    b.eval()
+    # no-grad evaluation (main.py:129): the same native launch sequence, forward only, equal to the per-module path
+    a.eval(), b.eval()
     with torch.no_grad():
-        assert b(d, x, y, m_type="test")[0].grad_fn is None
+        ea, eb = a(d, x, y, m_type="test"), b(d, x, y, m_type="test")
+    assert eb[0].grad_fn is None
+    for u, v in zip((ea[0], ea[2], ea[3][0], ea[3][1], ea[3][2], ea[4]), (eb[0], eb[2], eb[3][0], eb[3][1], eb[3][2], eb[4])):
+        assert torch.equal(u, v)
+    assert int(ea[1]) == int(eb[1])
