@@ -283,6 +283,16 @@ int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const floa
                      const float* recon, const float* y_hat, const float* mu, const float* logvar,
                      void* ws, size_t ws_bytes, mvh_stream_t side_stream /* NULL = internal */);
 
+/* The two halves of the forward on their own, for the inference-side callers that use the model piecewise
+ * (inference.py:98-131, crecon.py:167-192: net.encoder(x) ... net.sample(y, z)): the same launch sequences as inside
+ * mvh_vae_forward, same workspace.  encode: x [B,N,F] -> h [B,num_hidden] (cheb_VAE.py:261-273; drop_u_enc [B,H]
+ * uniforms or NULL).  decode: zy [B, num_classes + num_style] -> recon [B,N,F] (cheb_VAE.py:275-292; drop_u NULL or a
+ * buffer in the full-step layout [B*H | B*H | B*H | B*flat] of which the last two segments are read). */
+int mvh_vae_encode(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* const* params, const float* x,
+                   const float* drop_u_enc, int32_t B, float* h, void* ws, size_t ws_bytes);
+int mvh_vae_decode(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* const* params, const float* zy,
+                   const float* drop_u, int32_t B, float* recon, void* ws, size_t ws_bytes);
+
 /* Data-parallel overlap: make `stream` wait until the DENSE-layer weight gradients written by the
  * most recent mvh_vae_backward issued from this host thread on the current device are final -- classifier_layer,
  * z_mean, z_log_var, enc_lin, dec_lin, dec_lin_1, dec_lin_2: 98 % of the parameter bytes at default.cfg, and they

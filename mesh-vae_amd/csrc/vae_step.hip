@@ -195,13 +195,18 @@ extern "C" int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc) {
 #define TX(off) ((off) == kNoBits ? (float*)nullptr : (float*)((char*)ws + (off)))
 #define TRY(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
 
-extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
-                               const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
-                               const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
-                               float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu,
-                               float* logvar, void* ws, size_t ws_bytes) {
+// phases of the forward: the whole step, or only the encoder (x -> h) / only the decoder (zy -> recon) for the
+// inference-side callers (inference.py, crecon.py call net.encoder / net.sample on their own)
+enum { kPhEnc = 1, kPhHead = 2, kPhDec = 4, kPhLoss = 8, kPhAll = 15 };
+
+static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
+                            const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
+                            const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
+                            float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu,
+                            float* logvar, void* ws, size_t ws_bytes, int phases, float* h_out, const float* zy_in) {
   StepPlan p;
   TRY(build_plan(d, B, p));
+  if (phases == kPhAll)
   MVH_REQUIRE(P && x && y && x_gt && loss && correct && recon && kld && rec && z && y_hat && mu && logvar,
               "vae_forward: null tensor");
   MVH_REQUIRE(B > 0, "vae_forward: empty batch");
@@ -240,19 +245,24 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   }
   // ---- encoder (cheb_VAE.py:261-273)
   const float* cur = x;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n && (phases & kPhEnc); ++i) {
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), TX(p.txEnc[i]), B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
                            &d->down[i], F(p.encP[i]), BITS(p.encBits[i])));
     cur = F(p.encP[i]);
   }
-  TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], F(p.h), B, p.flat, p.H, MVH_ACT_RELU, u_enc, pd));
+  if (phases & kPhEnc)
+    TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], h_out ? h_out : F(p.h), B, p.flat, p.H, MVH_ACT_RELU,
+                       u_enc, pd));
   // ---- classifier + latent heads + reparameterisation (cheb_VAE.py:203-226)
-  TRY(mvh_vae_latent_fwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
-                         P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z));
+  if (phases & kPhHead)
+    TRY(mvh_vae_latent_fwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
+                           P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z));
+  if (!(phases & kPhDec)) return MVH_OK;
   // ---- decoder (cheb_VAE.py:275-292)
-  TRY(mvh_linear_fwd(stream, F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H, MVH_ACT_RELU, u_d1, pd));
+  TRY(mvh_linear_fwd(stream, zy_in ? zy_in : F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H,
+                     MVH_ACT_RELU, u_d1, pd));
   TRY(mvh_linear_fwd(stream, F(p.d1), P[ix.dl2W()], P[ix.dl2B()], F(p.d2), B, p.H, p.flat, MVH_ACT_RELU, u_d2, pd));
   // the first upsampling takes the dense head's output; the later ones are produced by the previous
   // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
@@ -269,11 +279,35 @@ extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, con
   TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
                          p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n]), nullptr, nullptr, nullptr,
                          F(p.weff_final)));
+  if (!(phases & kPhLoss)) return MVH_OK;
   // ---- loss (cheb_VAE.py:321-346)
   // (the gradient seeds of a d_loss = 1 backward come out of the same two launches)
   return loss_fwd_impl((hipStream_t)stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld,
                        correct, B, p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes, F(p.g_recon), F(p.d_mu), F(p.d_lv),
                        F(p.d_yhat));
+}
+
+extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
+                               const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
+                               const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
+                               float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu,
+                               float* logvar, void* ws, size_t ws_bytes) {
+  return vae_forward_impl(stream, d, P, x, y, x_gt, gt_f64, eps, drop_u, B, log_sigma, loss, correct, recon, kld, rec, z,
+                          y_hat, mu, logvar, ws, ws_bytes, kPhAll, nullptr, nullptr);
+}
+
+extern "C" int mvh_vae_encode(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,
+                              const float* drop_u_enc, int32_t B, float* h, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(P && x && h, "vae_encode: null tensor");
+  return vae_forward_impl(stream, d, P, x, nullptr, nullptr, 0, nullptr, drop_u_enc, B, 0.f, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, kPhEnc, h, nullptr);
+}
+
+extern "C" int mvh_vae_decode(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* zy,
+                              const float* drop_u, int32_t B, float* recon, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(P && zy && recon, "vae_decode: null tensor");
+  return vae_forward_impl(stream, d, P, nullptr, nullptr, nullptr, 0, nullptr, drop_u, B, 0.f, nullptr, nullptr, recon,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, kPhDec, nullptr, zy);
 }
 
 extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P,

@@ -72,6 +72,8 @@ SIGNATURES = {
     "mvh_vae_loss_fwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 4 + [_P, _Z]),
     "mvh_recon_postprocess": (ctypes.c_int, [_P] * 10 + [_I, _I]),
     "mvh_vae_wait_dense_grads": (ctypes.c_int, [_P]),
+    "mvh_vae_encode": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _I, _P, _P, _Z]),
+    "mvh_vae_decode": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _I, _P, _P, _Z]),
     "mvh_procrustes_stats": (ctypes.c_int, [_P] * 4 + [_I, _I]),
     "mvh_procrustes_apply": (ctypes.c_int, [_P] * 8 + [_I, _I]),
     "mvh_gather_normalize": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _I, ctypes.c_int64]),

@@ -457,6 +457,26 @@ class NativeStep:
                                      self.logvar.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
                                      self.side.cuda_stream if self.side is not None else None))
 
+    def encode(self, x, drop_u_enc=None):
+        """net.encoder(x) (cheb_VAE.py:261-273) as one native launch sequence -> h [B, num_hidden] (new tensor)."""
+        h = torch.empty(self.B, self.net.num_hidden, dtype=torch.float32, device=self.dev)
+        x = x.contiguous()
+        with torch.cuda.device(self.dev):
+            check(lib().mvh_vae_encode(torch.cuda.current_stream(self.dev).cuda_stream, ctypes.byref(self.desc), self._P,
+                                       x.data_ptr(), None if drop_u_enc is None else drop_u_enc.data_ptr(), self.B,
+                                       h.data_ptr(), self.ws.data_ptr(), self.ws_bytes))
+        return h
+
+    def decode(self, zy, drop_u=None):
+        """net.decoder(zy) (cheb_VAE.py:275-292) as one native launch sequence -> recon [B, N, F] (new tensor)."""
+        recon = torch.empty(self.B, self.net.num_nodes[0], self.net.filters[0], dtype=torch.float32, device=self.dev)
+        zy = zy.contiguous().to(torch.float32)
+        with torch.cuda.device(self.dev):
+            check(lib().mvh_vae_decode(torch.cuda.current_stream(self.dev).cuda_stream, ctypes.byref(self.desc), self._P,
+                                       zy.data_ptr(), None if drop_u is None else drop_u.data_ptr(), self.B,
+                                       recon.data_ptr(), self.ws.data_ptr(), self.ws_bytes))
+        return recon
+
     def _refresh_pointers(self):
         for i, p in enumerate(self.params):
             self._P[i], self._G[i] = p.data_ptr(), self.grads[i].data_ptr()

@@ -136,6 +136,10 @@ class cheb_VAE(torch.nn.Module):
     # ------------------------------------------------------------------ stages
     def encoder(self, x):
         self._prepare()
+        if x.dim() == 3 and self._native_ok(x):
+            ent = self._fused_entry(x.shape[0], x.device)
+            ent["gen"] += 1                          # (the step's workspace is reused: invalidates a pending fused backward)
+            return ent["step"].encode(x, self._drop_u(x.shape[0], self.num_hidden, x.device))
         for i in range(self.n_layers):
             x = F_hip.cheb_conv(x, self.cheb[i].weight, self.cheb[i].bias, self._lap[i], relu=True)
             x = F_hip.surface_pool(x, self._down[i])
@@ -165,6 +169,16 @@ class cheb_VAE(torch.nn.Module):
 
     def decoder(self, x):
         self._prepare()
+        if x.dim() == 2 and self._native_ok(x):
+            ent = self._fused_entry(x.shape[0], x.device)
+            ent["gen"] += 1
+            step, B_, H = ent["step"], x.shape[0], self.num_hidden
+            u = None
+            if self.training and self.dropout.p > 0.0:     # same draws, in the same order, as the per-module path
+                u = torch.empty(B_ * step.u_cols, device=x.device)
+                u[2 * B_ * H:3 * B_ * H] = torch.rand(B_, H, device=x.device).reshape(-1)
+                u[3 * B_ * H:] = torch.rand(B_, self.dec_lin_2.out_features, device=x.device).reshape(-1)
+            return ent["step"].decode(x, u)
         B, dev, p = x.shape[0], x.device, self.dropout.p
         x = F_hip.linear(x, self.dec_lin.weight, self.dec_lin.bias, relu=True,
                          drop_u=self._drop_u(B, self.num_hidden, dev), p=p)
@@ -194,22 +208,9 @@ class cheb_VAE(torch.nn.Module):
         """The whole forward as ONE autograd node over the native step (mvh_vae_forward / mvh_vae_backward):
         what `loss.backward()` in the reference's train loop (main.py:80) then triggers is a single C++ launch
         sequence instead of ~60 Python-driven autograd nodes -- bitwise the same numbers (same kernels)."""
-        from meshvae_hip.engine import NativeStep
         B, dev = x.shape[0], x.device
-        cache = self.__dict__.setdefault("_fused_cache", {})
-        ent = cache.get(B)
-        if ent is None:
-            if len(cache) >= 3:                      # (a workspace is ~12 MB per mesh: keep few batch sizes)
-                cache.pop(next(iter(cache)))
-            params = [p for _, p in self.named_parameters()]
-            flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in params), dtype=torch.float32, device=dev)
-            views, off = [], 0
-            for p in params:
-                views.append(flat[off:off + p.numel()].view_as(p))
-                off += -(-p.numel() // 64) * 64
-            ent = cache[B] = {"step": NativeStep(self, B, grads=views), "flat": flat, "views": views, "gen": 0}
+        ent = self._fused_entry(B, dev)
         step = ent["step"]
-        step._refresh_pointers()
         eps = None
         if m_type == "train":
             provider = getattr(self, "_eps_provider", None)
@@ -224,6 +225,28 @@ class cheb_VAE(torch.nn.Module):
         outs = _FusedModelFn.apply(ent, x.contiguous(), x_gt.contiguous(), y, eps, drop_u, *step.params)
         loss, correct, recon, kld, rec, z_, y_hat = outs
         return loss, correct, recon, [kld, rec, z_], y_hat
+
+    def _fused_entry(self, B, dev):
+        """Native step object (descriptor, workspace, gradient buffers) for batch size B, a few sizes cached."""
+        from meshvae_hip.engine import NativeStep
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        ent = cache.get(B)
+        if ent is None:
+            if len(cache) >= 3:                      # (a workspace is ~12 MB per mesh: keep few batch sizes)
+                cache.pop(next(iter(cache)))
+            params = [p for _, p in self.named_parameters()]
+            flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in params), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += -(-p.numel() // 64) * 64
+            ent = cache[B] = {"step": NativeStep(self, B, grads=views), "flat": flat, "views": views, "gen": 0}
+        ent["step"]._refresh_pointers()
+        return ent
+
+    def _native_ok(self, t):
+        """Piecewise inference calls (net.encoder / net.decoder under no_grad) take the native launch sequences."""
+        return getattr(self, "fused_step", True) and t.is_cuda and not torch.is_grad_enabled() and t.dtype == torch.float32
 
     def forward(self, data, x_gt, y, supervise=True, m_type="test"):
         self.supervise = supervise

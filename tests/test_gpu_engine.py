@@ -358,3 +358,36 @@ def test_module_forward_is_one_fused_autograd_node():
     for u, v in zip((ea[0], ea[2], ea[3][0], ea[3][1], ea[3][2], ea[4]), (eb[0], eb[2], eb[3][0], eb[3][1], eb[3][2], eb[4])):
         assert torch.equal(u, v)
     assert int(ea[1]) == int(eb[1])
+
+
+def test_piecewise_inference_calls_take_the_native_sequences():
+    """net.encoder / net.sample under no_grad (inference.py, crecon.py) run mvh_vae_encode / mvh_vae_decode: the
+    same kernels as the per-module path, so the results are identical -- in eval mode and, with the same torch seed,
+    with the dropout the reference leaves on in crecon.py."""
+    dev = torch.device("cuda:0")
+    B = 6
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 162, 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    a, b = _net(dev, dropout=0.3), _net(dev, dropout=0.3)
+    a.fused_step = False
+    for mode in ("eval", "train"):
+        for n_ in (a, b):
+            n_.train(mode == "train")
+        outs = []
+        for n_ in (a, b):
+            torch.manual_seed(77)
+            with torch.no_grad():
+                h = n_.encoder(x)
+                y_hat = n_.classifier(h)
+                mu = n_.z_mean(torch.cat([y.float(), h], -1))
+                rec = n_.sample(y, mu)
+                rec2 = n_.sample(1 - y, mu)
+            outs.append((h, y_hat, rec, rec2))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v), mode
+        assert outs[1][2].shape == (B, 162, 3)
+    # under grad mode the piecewise calls stay on the differentiable per-module path
+    b.train()
+    h = b.encoder(x)
+    assert h.requires_grad
