@@ -391,3 +391,30 @@ def test_piecewise_inference_calls_take_the_native_sequences():
     b.train()
     h = b.encoder(x)
     assert h.requires_grad
+
+
+def test_bench_line_contract():
+    """bench.py prints exactly one JSON line on stdout carrying the keys the driver reads, the roofline object of
+    the dominant kernel and the CPU baseline (one child process: the script redirects its own stdout)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--prewarm-steps", "20"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "meshes/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "meshes/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
