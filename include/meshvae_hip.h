@@ -204,6 +204,13 @@ int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* e
                   float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float grad_scale, int32_t* step_count);
 
+/* The same update with the step number t >= 1 counted by the caller (eager launch sequences: saves the counter-tick
+ * launch of mvh_adam_step, which exists so that a captured graph can be replayed); *step_count is set to t, so a later
+ * mvh_adam_step / graph capture continues from there. */
+int mvh_adam_step_counted(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
+                          float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float grad_scale, int32_t* step_count, int32_t step);
+
 /* ---- around the step: what main.py:88-93 / :139-145 do on the HOST with numpy after
  * every batch -- de-normalise the reconstruction (out * std + mean, per vertex), undo the Procrustes
  * alignment of data.py:144 (bmm(mesh * s, R) + m) and take the per-vertex Euclidean distance to the

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mvh_procrustes_apply": (ctypes.c_int, [_P] * 8 + [_I, _I]),
     "mvh_gather_normalize": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _I, ctypes.c_int64]),
     "mvh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P]),
+    "mvh_adam_step_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P, _I]),
     "mvh_sizeof_vae_desc": (_Z, []),
     "mvh_sizeof_csr": (_Z, []),
     "mvh_vae_step_ws_bytes": (_Z, [ctypes.POINTER(VaeDesc), _I]),

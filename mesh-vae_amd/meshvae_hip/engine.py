@@ -94,11 +94,22 @@ class FusedAdam:
 
     def step(self, grad_scale=1.0):
         f = self.flat
-        with torch.cuda.device(f.param.device):
-            check(lib().mvh_adam_step(torch.cuda.current_stream(f.param.device).cuda_stream, f.param.data_ptr(),
-                                      f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                      f.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.weight_decay, float(grad_scale), self.step_count.data_ptr()))
+        dev = f.param.device
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            args = (f.param.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.numel,
+                    self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale),
+                    self.step_count.data_ptr())
+            if torch.cuda.is_current_stream_capturing() or os.environ.get("MESHVAE_ADAM_TICK") == "1":
+                # replayable form: the step number lives on the device and a tick kernel advances it
+                self._host_step = None
+                check(lib().mvh_adam_step(st, *args))
+            else:
+                # eager: the host counts (one launch less); the kernel keeps the device counter in sync
+                if getattr(self, "_host_step", None) is None:
+                    self._host_step = int(self.step_count.item())     # once: after construction / after graph replays
+                self._host_step += 1
+                check(lib().mvh_adam_step_counted(st, *args, self._host_step))
 
 
 def scheduled_lr(config, epoch, current_lr):
@@ -284,6 +295,7 @@ class TrainStep:
             self.graph_fb.replay()
             self.flat.all_reduce(self.group)
             self.graph_opt.replay()
+            self.opt._host_step = None          # the replay advanced the device-side step counter
         else:
             self._fwd_bwd()
             if not self._all_reduce_overlapped():
@@ -380,6 +392,7 @@ class ClassifierStep:
                 self.capture()
             self.graph_fb.replay()
             self.graph_opt.replay()
+            self.opt._host_step = None          # the replay advanced the device-side step counter
         else:
             self._fwd_bwd()
             self.opt.step(1.0)
