@@ -179,6 +179,11 @@ def main():
                     help="untimed steps run BEFORE the --warmup steps (clock / power-state ramp of a cold GPU: the "
                          "first process on a fresh box was seen 25 %% slow otherwise).  A step COUNT, not a duration: "
                          "every rank must issue the same number of gradient all-reduces.  0 disables")
+    ap.add_argument("--rehearse-allreduce", action="store_true",
+                    help="1 GPU: bring up a 1-rank RCCL group and run the gradient collective anyway (rehearsal of the "
+                         "multi-GPU stream hand-over on a one-GPU box)")
+    ap.add_argument("--ar-overlap", action="store_true", help="two-bucket overlapped gradient all-reduce (opt-in)")
+    ap.add_argument("--seed", type=int, default=666, help="weights: this seed on every rank; noise: seed + rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
@@ -192,7 +197,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    force_dist = os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") == "1"   # 1-rank rehearsal of the RCCL path
+    force_dist = args.rehearse_allreduce                             # 1-rank rehearsal of the RCCL path
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
@@ -206,8 +211,11 @@ def main():
     net = build_model(dev)
     net.train()
     B = args.batch
+    # weights: same seed on every rank AND a broadcast from rank 0 inside TrainStep; reparameterisation noise and
+    # dropout masks: private generators seeded seed + rank, so no two ranks draw the same noise for their shards
     step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=bool(args.graph), m_type="train",
-                     n_micro=args.micro)
+                     n_micro=args.micro, noise_seed=args.seed, rehearse_allreduce=args.rehearse_allreduce,
+                     overlap_allreduce=args.ar_overlap)
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B, 4998, 3, generator=g)
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
@@ -246,7 +254,8 @@ def main():
         out = {
             "metric": "meshes/sec fwd+bwd, 5k-vertex ChebConv VAE",
             "value": meshes_per_s, "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "prewarm_steps": max(args.prewarm_steps, 0),
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: default.cfg 5k-vertex K=6 ChebConv VAE train step "
                                    "(fwd+bwd+grad all-reduce+Adam), 64 meshes/GPU, fp32, dropout 0.2",

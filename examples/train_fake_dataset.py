@@ -6,7 +6,7 @@ factory (model.get_model builds the hierarchy from the template OBJ), the native
 optimizer and LR table (main.py:251,266-269), and the evaluation block of main.py:129-159 (de-normalise, inverse
 Procrustes, per-vertex error) -- nothing touches the host between the loader and the reported numbers.
 
-    python examples/train_fake_dataset.py [--meshes 64] [--epochs 3] [--batch 16] [--template tests/golden/template_5k.npz]
+    python examples/train_fake_dataset.py [--meshes 64] [--epochs 3] [--batch 16] [--template some.obj]
 """
 import argparse
 import os
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--meshes", type=int, default=64)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--template", default=os.path.join(ROOT, "tests", "golden", "template_5k.npz"))
+    ap.add_argument("--template", default=None, help="template OBJ (default: this repo's procedural 4998-vertex torus)")
     ap.add_argument("--workdir", default=None)
     a = ap.parse_args()
     from meshvae_hip.engine import TrainStep
@@ -35,8 +35,13 @@ def main():
     from preprocess import DeviceDataset, list_meshes, save_obj
 
     work = a.workdir or tempfile.mkdtemp(prefix="meshvae_fake_")
-    z = np.load(a.template)
-    verts, faces = z["verts"], z["faces"]
+    if a.template:
+        import mesh_operations
+        verts, faces = mesh_operations.read_obj(a.template)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from meshgen import torus_mesh
+        verts, faces = torus_mesh(51, 98)
     data_dir = os.path.join(work, "data")
     os.makedirs(data_dir, exist_ok=True)
     template_obj = os.path.join(work, "template.obj")
@@ -58,7 +63,7 @@ def main():
     t0 = time.perf_counter()
     index, labels = list_meshes(config)
     n_train = int(0.75 * len(index)) // a.batch * a.batch
-    template = np.load(a.template)["verts"]
+    template = verts
     train = DeviceDataset.from_directory(index[:n_train], config, labels, template, dtype="train", device=dev)
     test = DeviceDataset.from_directory(index[n_train:], config, labels, template, dtype="test", device=dev)
     print(f"loader: {time.perf_counter() - t0:.2f} s for {len(index)} OBJ files (read + align + normalise)")

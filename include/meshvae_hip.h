@@ -87,6 +87,13 @@ int mvh_version(void);
 const char* mvh_last_error(void);
 /* Device properties of the current HIP device (arch string e.g. "gfx950"). */
 int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
+/* Debug / A-B switches (no reference counterpart).  They live in ONE struct that is filled when the
+ * library is loaded from MESHVAE_DEBUG="key=value,..." and is never re-read from the environment;
+ * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch,
+ * no_gstack_mfma, no_dw_mfma, no_xcd_remap.  mvh_debug_set changes one switch in-process (the tests
+ * run both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
+int mvh_debug_set(const char* key, int32_t value);
+int32_t mvh_debug_get(const char* key);
 
 /* ---- row P: MessagePassing.propagate (nn/conv.py:242-331 with __collect__ :171-229,
  * message :579-581, aggregate :346-364).  y[b,r,:] = add[b,r,:] + alpha * sum_e val[e] *
@@ -199,17 +206,21 @@ int mvh_vae_loss_bwd(mvh_stream_t stream, const float* recon, const void* x_gt, 
 /* ---- train-loop optimizer (reference main.py:251, :80-81: torch.optim.Adam with coupled L2
  * weight_decay) over the flat parameter buffer.  step_count is a device int32 incremented by
  * the call (so the step is hipGraph-replayable); grad is multiplied by grad_scale first
- * (1/world_size after a sum all-reduce). */
+ * (1/world_size after a sum all-reduce).  Elements [skip_lo, skip_hi) of the buffers are left untouched
+ * (skip_lo >= skip_hi: none): torch.optim.Adam skips parameters whose .grad is None -- dec_lin_1,
+ * which the forward never uses (cheb_VAE.py:165), keeps its initial values in the reference. */
 int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
                   float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, float grad_scale, int32_t* step_count);
+                  float weight_decay, float grad_scale, int32_t* step_count, int64_t skip_lo,
+                  int64_t skip_hi);
 
 /* The same update with the step number t >= 1 counted by the caller (eager launch sequences: saves the counter-tick
  * launch of mvh_adam_step, which exists so that a captured graph can be replayed); *step_count is set to t, so a later
  * mvh_adam_step / graph capture continues from there. */
 int mvh_adam_step_counted(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
                           float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, float grad_scale, int32_t* step_count, int32_t step);
+                          float weight_decay, float grad_scale, int32_t* step_count, int32_t step,
+                          int64_t skip_lo, int64_t skip_hi);
 
 /* ---- around the step: what main.py:88-93 / :139-145 do on the HOST with numpy after
  * every batch -- de-normalise the reconstruction (out * std + mean, per vertex), undo the Procrustes

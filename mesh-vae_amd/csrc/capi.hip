@@ -25,9 +25,64 @@ int check_csr(const mvh_csr_t* op, const char* what) {
   return MVH_OK;
 }
 
+struct DebugKey {
+  const char* name;
+  int DebugCfg::*field;
+};
+static const DebugKey kDebugKeys[] = {
+    {"force_generic", &DebugCfg::force_generic}, {"l0_wide", &DebugCfg::l0_wide},
+    {"side_prio", &DebugCfg::side_prio},         {"no_side", &DebugCfg::no_side},
+    {"no_tstack", &DebugCfg::no_tstack},         {"tail_main", &DebugCfg::tail_main},
+    {"fork_batch", &DebugCfg::fork_batch},       {"no_gstack_mfma", &DebugCfg::no_gstack_mfma},
+    {"no_dw_mfma", &DebugCfg::no_dw_mfma},       {"no_xcd_remap", &DebugCfg::no_xcd_remap},
+};
+
+static int DebugCfg::*find_debug_key(const char* key, size_t len) {
+  for (const DebugKey& k : kDebugKeys)
+    if (strlen(k.name) == len && strncmp(k.name, key, len) == 0) return k.field;
+  return nullptr;
+}
+
+static DebugCfg parse_debug_env() {
+  DebugCfg c;
+  const char* e = getenv("MESHVAE_DEBUG");
+  while (e && *e) {
+    const char* end = strchr(e, ',');
+    const size_t len = end ? (size_t)(end - e) : strlen(e);
+    const char* eq = (const char*)memchr(e, '=', len);
+    if (eq) {
+      if (int DebugCfg::*f = find_debug_key(e, (size_t)(eq - e))) c.*f = atoi(eq + 1);
+      else fprintf(stderr, "libmeshvae_hip: unknown MESHVAE_DEBUG key '%.*s'\n", (int)(eq - e), e);
+    }
+    e = end ? end + 1 : nullptr;
+  }
+  if (c.fork_batch < 1) c.fork_batch = 1;
+  if (c.fork_batch > 4) c.fork_batch = 4;
+  return c;
+}
+
+DebugCfg& dbg() {
+  static DebugCfg c = parse_debug_env();
+  return c;
+}
+static const DebugCfg& dbg_at_load = dbg();  // parsed when the library is loaded, not at the first launch
+
 }  // namespace mvh
 
 using namespace mvh;
+
+extern "C" int mvh_debug_set(const char* key, int32_t value) {
+  MVH_REQUIRE(key != nullptr, "debug_set: null key");
+  int DebugCfg::*f = find_debug_key(key, strlen(key));
+  MVH_REQUIRE(f != nullptr, "debug_set: unknown key '%s'", key);
+  dbg().*f = value;
+  return MVH_OK;
+}
+
+extern "C" int32_t mvh_debug_get(const char* key) {
+  int DebugCfg::*f = key ? find_debug_key(key, strlen(key)) : nullptr;
+  return f ? dbg().*f : -1;
+}
 
 extern "C" int mvh_version(void) { return 100; }
 

@@ -250,8 +250,7 @@ static int launch_gstack(hipStream_t st, const float* dout, const float* out, co
     MVH_LAUNCH_CHECK();
     return MVH_OK;
   }
-  static const char* no_mfma = getenv("MESHVAE_NO_GSTACK_MFMA");
-  if (Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !(no_mfma && no_mfma[0] == '1') &&
+  if (Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !dbg().no_gstack_mfma &&
       (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)W | (uintptr_t)G | (uintptr_t)g0) & 15) == 0) {
     const long long nblk = (rows + 15) / 16;
     const long long waves = min(nblk, 8192ll);
@@ -498,8 +497,7 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
   const int KC = K * Cin;
   const int n = (KC + 1) * Cout;
   int G = dw_grid(rows);
-  static const char* no_mfma = getenv("MESHVAE_NO_DW_MFMA");
-  if ((Cout == 16 || Cout == 32) && rows >= 4096 && !(no_mfma && no_mfma[0] == '1')) {
+  if ((Cout == 16 || Cout == 32) && rows >= 4096 && !dbg().no_dw_mfma) {
     // big levels: streaming MFMA reduction (k_cheb_dw_mfma); G blocks x 4 waves, contiguous row ranges
     const long long waves = max(4ll, min(2048ll, rows / 256));
     G = min(G, (int)((waves + 3) / 4));
@@ -693,8 +691,7 @@ k_relu_bits(const float* __restrict__ out, uint8_t* __restrict__ bits, long long
 }
 
 static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
-  const char* e = getenv("MESHVAE_FORCE_GENERIC");
-  if (e && e[0] == '1') return false;
+  if (dbg().force_generic) return false;
   return lap->sub && lap->n_active > 0 && 4 * lap->n_active <= N && lap->sub->n_rows == lap->n_active &&
          (size_t)(K + 2) * Cin * Cout * sizeof(float) + 1024 <= kSplitScratchBytes;
 }

@@ -575,8 +575,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
                     const uint8_t* out_bits, DwReduceEntry* defer) {
   *handled = false;
-  const char* e = getenv("MESHVAE_FORCE_GENERIC");
-  if (e && e[0] == '1') return MVH_OK;
+  if (dbg().force_generic) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
     return MVH_OK;

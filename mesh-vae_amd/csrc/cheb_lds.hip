@@ -542,11 +542,6 @@ int launch_pack_all(hipStream_t st, const PackTable& t) {
   return MVH_OK;
 }
 
-static bool force_generic() {  // read per call: the tests flip it inside one process
-  const char* e = getenv("MESHVAE_FORCE_GENERIC");
-  return e && e[0] == '1';
-}
-
 template <int CQ, int VPT, int TCT, int PW, bool BWD>
 static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   auto kern = k_cheb_lds<CQ, VPT, TCT, PW, BWD>;
@@ -593,7 +588,7 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   *handled = false;
   const float* prepacked = o.prepacked;
   if (!wpack && !prepacked) return MVH_OK;
-  if (force_generic()) return MVH_OK;
+  if (dbg().force_generic) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
     return MVH_OK;
@@ -608,11 +603,9 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   else if (N + 1 <= 2048) { vpt = 2; threads = (((N + 2) / 2 + 63) / 64) * 64; }
   else if (N + 1 <= 5120 && CQ <= 16 && !(lap->flags & MVH_CSR_ELL_OVERFLOW)) {
     // 1024 threads x 5 vertices (4 waves/SIMD, 128 VGPRs) measured 1-5 % faster per step than 512 x 10
-    // (2 waves/SIMD, 256 VGPRs) in both directions; MESHVAE_L0_CFG=1 selects the latter for A/B runs
+    // (2 waves/SIMD, 256 VGPRs) in both directions; the debug switch l0_wide selects the latter for A/B runs
     // (the GPU tests pass under both)
-    const char* cfg = getenv("MESHVAE_L0_CFG");  // (read per call: the tests flip it inside one process)
-    const bool wide = cfg && cfg[0] == '1';
-    if (wide) { vpt = 10; threads = 512; } else { vpt = 5; threads = 1024; }
+    if (dbg().l0_wide) { vpt = 10; threads = 512; } else { vpt = 5; threads = 1024; }
   }
   else return MVH_OK;
   const int pw = lap->ell_pairs > 4 ? 8 : 4;

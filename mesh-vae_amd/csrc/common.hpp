@@ -37,6 +37,24 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int check_csr(const mvh_csr_t* op, const char* what);
 
+// Debug / A-B switches of the whole library: ONE struct, filled once when the library is loaded from
+// MESHVAE_DEBUG="key=value,key=value" (keys = the member names) and changed afterwards only through
+// mvh_debug_set() (the tests flip force_generic / l0_wide inside one process).  No launcher reads the
+// environment.
+struct DebugCfg {
+  int force_generic = 0;   // 1: never take the LDS-resident kernels (general stack pipeline everywhere)
+  int l0_wide = 0;         // 1: 512 threads x 10 vertices at the 5k level instead of 1024 x 5
+  int side_prio = 0;       // -1 / +1: low / high queue priority for the weight-gradient lanes
+  int no_side = 0;         // 1: weight gradients inline on the main stream
+  int no_tstack = 0;       // 1: first-layer dW through the recurrence kernel instead of the saved stack
+  int tail_main = 1;       // 0: encoder layer 1's dW stays on the side lane
+  int fork_batch = 1;      // conv layers sharing one fork event (1..4)
+  int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
+  int no_dw_mfma = 0;
+  int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
+};
+DebugCfg& dbg();
+
 // ---- internal launchers shared between translation units (all async on `st`)
 int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, const float* add,
                 const float* z, float alpha, float beta, int B, int C, bool exact);

@@ -13,10 +13,12 @@ __global__ void k_adam_tick(int* step) { *step += 1; }
 __global__ void __launch_bounds__(256)
 k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
        long long n, float lr, float b1, float b2, float eps, float wd, float grad_scale,
-       int* __restrict__ step, int host_step) {
+       int* __restrict__ step, int host_step, long long skip_lo, long long skip_hi) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (host_step > 0 && i == 0) *step = host_step;
   if (i >= n) return;
+  // parameters that never receive a gradient (torch.optim.Adam skips `p.grad is None`: no decay, no state)
+  if (i >= skip_lo && i < skip_hi) return;
   const float t = host_step > 0 ? (float)host_step : (float)(*step);
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   float gi = g[i] * grad_scale;
@@ -36,7 +38,8 @@ using namespace mvh;
 
 extern "C" int mvh_adam_step(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
                              float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float grad_scale, int32_t* step_count) {
+                             float weight_decay, float grad_scale, int32_t* step_count, int64_t skip_lo,
+                             int64_t skip_hi) {
   MVH_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_count, "adam_step: null tensor");
   MVH_REQUIRE(n >= 0, "adam_step: bad size");
   hipStream_t st = (hipStream_t)stream;
@@ -44,18 +47,21 @@ extern "C" int mvh_adam_step(mvh_stream_t stream, float* param, const float* gra
   MVH_LAUNCH_CHECK();
   if (n == 0) return MVH_OK;
   hipLaunchKernelGGL(k_adam, dim3(cdiv(n, 256)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq,
-                     (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, 0);
+                     (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, 0, (long long)skip_lo,
+                     (long long)skip_hi);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
 
 extern "C" int mvh_adam_step_counted(mvh_stream_t stream, float* param, const float* grad, float* exp_avg,
                                      float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, float grad_scale, int32_t* step_count, int32_t step) {
+                                     float weight_decay, float grad_scale, int32_t* step_count, int32_t step,
+                                     int64_t skip_lo, int64_t skip_hi) {
   MVH_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_count, "adam_step: null tensor");
   MVH_REQUIRE(n > 0 && step > 0, "adam_step_counted: bad size or step");
   hipLaunchKernelGGL(k_adam, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
-                     (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, (int)step);
+                     (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_count, (int)step,
+                     (long long)skip_lo, (long long)skip_hi);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

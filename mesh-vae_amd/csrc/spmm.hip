@@ -190,11 +190,10 @@ int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, c
                 const float* z, float alpha, float beta, int B, int C, bool exact) {
   if (B == 0 || op->n_rows == 0 || C == 0) return MVH_OK;
   const bool v4 = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)z) % 16 == 0);
-  static const char* no_remap3 = getenv("MESHVAE_NO_XCD_REMAP");
   if (C == 3 && !exact && op->n_rows >= 4096) {  // big level, three channels: one lane per row
     const int wpm = cdiv(op->n_rows, 256);
     MVH_REQUIRE((long long)B * wpm < (1ll << 31), "spmm: grid too large");
-    const int remap = (B % 8 == 0 && wpm >= 16 && !(no_remap3 && no_remap3[0] == '1')) ? 1 : 0;
+    const int remap = (B % 8 == 0 && wpm >= 16 && !dbg().no_xcd_remap) ? 1 : 0;
     hipLaunchKernelGGL(k_spmm3, dim3(B * wpm), dim3(256), 0, st, op->rowptr, op->col, op->val, op->n_rows, op->n_cols,
                        x, y, add, z, alpha, beta, wpm, remap);
     MVH_LAUNCH_CHECK();
@@ -206,9 +205,8 @@ int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, c
   const long long grid_ll = (long long)B * wg_per_mesh;
   MVH_REQUIRE(grid_ll < (1ll << 31), "spmm: grid too large");
   const int grid = (int)grid_ll;
-  static const char* no_remap = getenv("MESHVAE_NO_XCD_REMAP");
   // (only worth it when one mesh is big enough to thrash: small levels keep the plain order)
-  const int xcd_remap = (B % 8 == 0 && wg_per_mesh >= 16 && !(no_remap && no_remap[0] == '1')) ? 1 : 0;
+  const int xcd_remap = (B % 8 == 0 && wg_per_mesh >= 16 && !dbg().no_xcd_remap) ? 1 : 0;
 #define MVH_SPMM(V, E)                                                                             \
   hipLaunchKernelGGL((k_spmm<V, E>), dim3(grid), dim3(256), 0, st, op->rowptr, op->col, op->val,   \
                      op->n_rows, op->n_cols, x, y, add, z, alpha, beta, C, wg_per_mesh, xcd_remap)

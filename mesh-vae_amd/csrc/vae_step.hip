@@ -160,10 +160,10 @@ static SideStream* side_for_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream& s = side[dev];
   if (!s.stream) {
-    // MESHVAE_SIDE_PRIO=low|high: queue priority of the two weight-gradient lanes relative to the caller's stream
+    // debug switch side_prio = -1 / +1: queue priority of the two weight-gradient lanes relative to the caller's stream
     int lo = 0, hi = 0, prio = 0;
-    const char* pe = getenv("MESHVAE_SIDE_PRIO");
-    if (pe && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = (pe[0] == 'l') ? lo : (pe[0] == 'h') ? hi : 0;
+    const int pe = dbg().side_prio;
+    if (pe != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = pe < 0 ? lo : hi;
     if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     if (hipStreamCreateWithPriority(&s.dense, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
@@ -326,10 +326,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward: could not create the side stream");
   hipStream_t sstream = side_stream ? (hipStream_t)side_stream : side->stream;
-  {
-    static const char* no_side = getenv("MESHVAE_NO_SIDE");
-    if (no_side && no_side[0] == '1') sstream = main;  // debugging aid: weight gradients on the main chain
-  }
+  if (dbg().no_side) sstream = main;  // debugging aid: weight gradients on the main chain
   // dense-layer weight gradients: their own lane (they would delay the conv dW chain on `sstream`)
   hipStream_t dstream = (sstream == main) ? main : (side_stream ? sstream : side->dense);
   void* sm = (char*)ws + p.scratch_main;
@@ -338,16 +335,15 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
   const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
-                          d->down[0].n_rows == p.Nn[1] && !getenv("MESHVAE_NO_TSTACK");
+                          d->down[0].n_rows == p.Nn[1] && !dbg().no_tstack;
   hipEvent_t ev_tstack = nullptr;
-  static const char* tail_env = getenv("MESHVAE_TAIL_MAIN");
-  const bool tail_on_main = use_tstack && sstream != main && !(tail_env && tail_env[0] == '0');
+  const bool tail_on_main = use_tstack && sstream != main && dbg().tail_main != 0;
   DwReduceTable red;        // pending dW reductions: one launch after the join
   red.n = 0;
   // fork: the weight-gradient kernels of a conv layer run on the side stream once its dout exists.
   // The launches go through a small queue so that several layers can share one fork (event record
   // on the main stream + wait on the side stream): every queued item's inputs exist when it is
-  // queued, so forking later is always safe.  MEASURED: sharing forks (MESHVAE_FORK_BATCH=2..4) is
+  // queued, so forking later is always safe.  MEASURED: sharing forks (debug switch fork_batch = 2..4) is
   // 3 % SLOWER than one fork per layer (the default, 1) -- the ~7 us gaps a rocprofv3 timeline
   // shows at the forks are tracing overhead, while starting a layer's dW later lengthens the tail.
   struct PendingDw {
@@ -363,11 +359,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   PendingDw pending[4];
   int n_pending = 0;
-  static const int fork_batch = [] {
-    const char* e = getenv("MESHVAE_FORK_BATCH");
-    const int v = e ? atoi(e) : 1;
-    return v < 1 ? 1 : (v > 4 ? 4 : v);
-  }();
+  const int fork_batch = dbg().fork_batch < 1 ? 1 : (dbg().fork_batch > 4 ? 4 : dbg().fork_batch);
   auto flush_dw = [&](bool also_dense) -> int {  // one event for everything queued (+ the dense lane)
     if (n_pending == 0 && !also_dense) return MVH_OK;
     if (sstream != main) {
@@ -496,7 +488,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     if (i > 0) {
       // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible);
       // with the stack path layer 0 costs the main stream only ~10 us, so layer 1's dW runs there after it
-      // instead of at the end of the side lane's backlog (MESHVAE_TAIL_MAIN=0: side lane as usual)
+      // instead of at the end of the side lane's backlog (debug switch tail_main = 0: side lane as usual)
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mvh_version": (ctypes.c_int, []),
     "mvh_last_error": (ctypes.c_char_p, []),
     "mvh_device_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]),
+    "mvh_debug_set": (ctypes.c_int, [ctypes.c_char_p, _I]),
+    "mvh_debug_get": (_I, [ctypes.c_char_p]),
     "mvh_spmm": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _F, _F, _I, _I, _I]),
     "mvh_pool_fwd": (ctypes.c_int, [_P, _CSR, _P, _P, _I, _I]),
     "mvh_pool_bwd": (ctypes.c_int, [_P, _CSR, _P, _P, _I, _I]),
@@ -77,8 +79,10 @@ SIGNATURES = {
     "mvh_procrustes_stats": (ctypes.c_int, [_P] * 4 + [_I, _I]),
     "mvh_procrustes_apply": (ctypes.c_int, [_P] * 8 + [_I, _I]),
     "mvh_gather_normalize": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P, _P, _P, _P, _I, ctypes.c_int64]),
-    "mvh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P]),
-    "mvh_adam_step_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P, _I]),
+    "mvh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P,
+                                      ctypes.c_int64, ctypes.c_int64]),
+    "mvh_adam_step_counted": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, _F, _F, _F, _F, _F, _F, _P, _I,
+                                              ctypes.c_int64, ctypes.c_int64]),
     "mvh_sizeof_vae_desc": (_Z, []),
     "mvh_sizeof_csr": (_Z, []),
     "mvh_vae_step_ws_bytes": (_Z, [ctypes.POINTER(VaeDesc), _I]),
@@ -110,6 +114,22 @@ def lib():
 def check(rc):
     if rc != 0:
         raise MeshVaeHipError(f"libmeshvae_hip error {rc}: {lib().mvh_last_error().decode()}")
+
+
+class debug_switch:
+    """Context manager: set one of the library's debug switches (include/meshvae_hip.h, mvh_debug_set) and
+    restore it afterwards.  Test / A-B tooling; the product never calls it."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key.encode(), int(value)
+
+    def __enter__(self):
+        self.old = lib().mvh_debug_get(self.key)
+        check(lib().mvh_debug_set(self.key, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().mvh_debug_set(self.key, self.old))
 
 
 def device_info():

@@ -9,7 +9,6 @@ gradients live in two contiguous buffers so no bucketing copies exist; `dec_lin_
 used, cheb_VAE.py:165) stays in the buffers with a zero gradient.
 """
 import ctypes
-import os
 
 import torch
 import torch.distributed as dist
@@ -69,25 +68,62 @@ class FlatParams:
             return None
         return self.offsets[k]
 
-    def all_reduce(self, group=None):
-        """Sum all-reduce of the flat gradient buffer (one collective per step)."""
-        if dist.is_available() and dist.is_initialized() and (
-                dist.get_world_size(group) > 1 or os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") == "1"):
-            # (the env switch runs the collective on a 1-rank group too: the only way to rehearse the RCCL
-            # stream hand-over of the multi-GPU path on a one-GPU box)
+    NO_GRAD = ("dec_lin_1.",)   # parameters the forward never touches (cheb_VAE.py:165): .grad stays None in the reference
+
+    def no_grad_range(self):
+        """[lo, hi) floats of the flat buffers covered by parameters that never receive a gradient (contiguous
+        in cheb_VAE's registration order); (0, 0) when there are none."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(self.NO_GRAD)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return (0, 0)
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.numel
+        return (self.offsets[idx[0]], hi)
+
+    def all_reduce(self, group=None, always=False):
+        """Sum all-reduce of the flat gradient buffer (one collective per step).  `always` runs the collective
+        on a 1-rank group too: the only way to rehearse the RCCL stream hand-over of the multi-GPU path on a
+        one-GPU box (bench.py --rehearse-allreduce)."""
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             return dist.get_world_size(group)
         return 1
+
+    def broadcast(self, group=None, src=0):
+        """Every rank takes rank `src`'s parameters (one collective over the flat buffer).  Data-parallel
+        replicas must start identical; seeding every rank alike gives that only as long as nothing else
+        has consumed the generator, so the engine does not rely on it."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.param, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+            return True
+        return False
+
+
+def rank_generators(seed, rank, device=None):
+    """Per-rank noise streams of a data-parallel job: (host generator for the reparameterisation noise, device
+    generator for the dropout uniforms or None on a CPU-only caller), both seeded `seed + rank` so that no two
+    ranks draw the same eps / masks for their shards (same seed everywhere = every rank would see the SAME
+    noise on different meshes, i.e. correlated gradient noise across the global batch)."""
+    host = torch.Generator().manual_seed(int(seed) + int(rank))
+    dev_gen = None
+    if device is not None and torch.device(device).type == "cuda":
+        dev_gen = torch.Generator(device=device).manual_seed(int(seed) + int(rank))
+    return host, dev_gen
 
 
 class FusedAdam:
     """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (reference main.py:251) as one
     HIP kernel over the flat buffers (mvh_adam_step)."""
 
-    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, device_counter=False):
+        """device_counter: always use the replayable form (step number on the device, advanced by a tick kernel);
+        default: only inside a stream capture."""
         if not flat.param.is_cuda:
             raise RuntimeError("FusedAdam runs on MI355X only (there is no CPU fallback)")
         self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.device_counter = bool(device_counter)
+        # [lo, hi) of the flat buffer that gets no update: parameters without a gradient (torch.optim.Adam skips
+        # `p.grad is None`; cheb_VAE's unused dec_lin_1 stays at its initial values in the reference)
+        self.skip = flat.no_grad_range()
         self.exp_avg = torch.zeros_like(flat.param)
         self.exp_avg_sq = torch.zeros_like(flat.param)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=flat.param.device)
@@ -100,16 +136,16 @@ class FusedAdam:
             args = (f.param.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.numel,
                     self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale),
                     self.step_count.data_ptr())
-            if torch.cuda.is_current_stream_capturing() or os.environ.get("MESHVAE_ADAM_TICK") == "1":
+            if torch.cuda.is_current_stream_capturing() or self.device_counter:
                 # replayable form: the step number lives on the device and a tick kernel advances it
                 self._host_step = None
-                check(lib().mvh_adam_step(st, *args))
+                check(lib().mvh_adam_step(st, *args, *self.skip))
             else:
                 # eager: the host counts (one launch less); the kernel keeps the device counter in sync
                 if getattr(self, "_host_step", None) is None:
                     self._host_step = int(self.step_count.item())     # once: after construction / after graph replays
                 self._host_step += 1
-                check(lib().mvh_adam_step_counted(st, *args, self._host_step))
+                check(lib().mvh_adam_step_counted(st, *args, self._host_step, *self.skip))
 
 
 def scheduled_lr(config, epoch, current_lr):
@@ -139,11 +175,25 @@ class TrainStep:
     """
 
     def __init__(self, net, batch, lr=1e-3, weight_decay=5e-4, use_graph=True, m_type="train", group=None,
-                 native=True, n_micro=1):
+                 native=True, n_micro=1, noise_seed=None, rehearse_allreduce=False, overlap_allreduce=False):
+        """noise_seed: reparameterisation noise and dropout uniforms come from generators private to this step,
+        seeded `noise_seed + rank` (rank_generators).  None on a single rank keeps the reference's behaviour --
+        the process-wide default generators (cheb_VAE.py:316) -- and on a multi-rank group means 666.
+        rehearse_allreduce: run the gradient collective even on a 1-rank group; overlap_allreduce: the
+        two-bucket form of _all_reduce_overlapped (opt-in until an 8-GPU measurement says otherwise)."""
         self.net, self.B, self.m_type, self.group = net, batch, m_type, group
         self.dev = next(net.parameters()).device
         self.flat = FlatParams(net)
+        self.flat.broadcast(group)                  # replicas start from rank 0's parameters, whatever the seeds were
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        self.rehearse_allreduce, self.overlap_allreduce = bool(rehearse_allreduce), bool(overlap_allreduce)
+        world_now = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if noise_seed is None and world_now > 1:
+            noise_seed = 666
+        self.host_gen = self.dev_gen = None
+        if noise_seed is not None:
+            rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+            self.host_gen, self.dev_gen = rank_generators(noise_seed, rank, self.dev)
         n0, f0 = net.num_nodes[0], net.filters[0]
         self.x = torch.zeros(batch, n0, f0, device=self.dev)
         self.x_gt = torch.zeros(batch, n0, f0, device=self.dev)
@@ -155,7 +205,9 @@ class TrainStep:
         self.graph_fb = self.graph_opt = None
         self._out = None
         self._comm = None      # stream of the overlapped dense-gradient all-reduce (created on first use)
-        net._eps_provider = lambda B, Z, device: self.eps      # static buffer (graph-safe)
+        # static buffer (graph-safe), only for the batch size it was built for: any other call of the module
+        # (a different B through net(...)) draws fresh host noise as the reference does
+        net._eps_provider = lambda B, Z, device: self.eps if (B == self.B and Z == self.eps.shape[1]) else None
         net._prepare()                                         # topology upload must precede any capture
         # native=True: the whole forward+backward is one C++ launch sequence (mvh_vae_forward/backward);
         # native=False: the per-module autograd path (what main.py drives through model.forward).
@@ -212,7 +264,8 @@ class TrainStep:
             cur = torch.cuda.current_stream(self.dev)
             mb = self.B // self.n_micro
             # dropout uniforms of every chain are drawn first, in chain order, on the caller's stream
-            us = [torch.rand(mb * nat.u_cols, device=self.dev) if train else None for nat in self.native]
+            us = [torch.rand(mb * nat.u_cols, device=self.dev, generator=self.dev_gen) if train else None
+                  for nat in self.native]
             for st, _ in self.streams:      # fork every chain BEFORE chain 0 queues its work on `cur`
                 if st is not None:
                     st.wait_stream(cur)
@@ -270,7 +323,7 @@ class TrainStep:
         buf, ev = self._eps_ring[self._eps_i]
         self._eps_i = (self._eps_i + 1) % len(self._eps_ring)
         ev.synchronize()                                   # the copy that used this buffer 8 steps ago
-        torch.normal(mean=0, std=1, size=(self.B, self.net.z), out=buf)
+        torch.normal(mean=0, std=1, size=(self.B, self.net.z), out=buf, generator=self.host_gen)
         self.eps.copy_(buf, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
 
@@ -293,13 +346,13 @@ class TrainStep:
             if self.graph_fb is None:
                 self.capture()
             self.graph_fb.replay()
-            self.flat.all_reduce(self.group)
+            self.flat.all_reduce(self.group, always=self.rehearse_allreduce)
             self.graph_opt.replay()
             self.opt._host_step = None          # the replay advanced the device-side step counter
         else:
             self._fwd_bwd()
             if not self._all_reduce_overlapped():
-                self.flat.all_reduce(self.group)
+                self.flat.all_reduce(self.group, always=self.rehearse_allreduce)
             self.opt.step(scale)
         return self.out
 
@@ -311,15 +364,15 @@ class TrainStep:
         (80 KB at default.cfg) are reduced after it.  The host has enqueued the whole backward long before the GPU
         gets there, so issuing the collective "late" from the host still starts it early on the device.  Same
         call order on every rank (dense bucket, then conv bucket).
-        OPT-IN (MESHVAE_AR_OVERLAP=1).  Measured on one GPU with a 1-rank RCCL group (tools/dist_overhead3.sh):
+        OPT-IN (overlap_allreduce=True; bench.py --ar-overlap).  Measured on one GPU with a 1-rank RCCL group (tools/dist_overhead3.sh):
         the second collective costs 17 us of fixed overhead per step (0.664 vs 0.647 ms), so it pays only where
         the 2.8 MB all-reduce takes clearly longer than an 80 KB one plus that -- which this one-GPU pool cannot
         measure; the default stays ONE collective after the backward."""
         if not (dist.is_available() and dist.is_initialized()) or self.native is None or self.n_micro != 1:
             return False
-        if dist.get_world_size(self.group) <= 1 and os.environ.get("MESHVAE_ALLREDUCE_ALWAYS") != "1":
+        if dist.get_world_size(self.group) <= 1 and not self.rehearse_allreduce:
             return False
-        if os.environ.get("MESHVAE_AR_OVERLAP") != "1":
+        if not self.overlap_allreduce:
             return False
         split = self.flat.conv_dense_split()
         if split is None:

@@ -90,25 +90,27 @@ def procrustes(data1, data2, device="cuda:0"):
 
 
 def list_meshes(config, get_sex_from_file_name=True):
-    """(dataset_index, labels) of the .obj files under config['root_dir'] (reference data.py:40-72): sorted names,
-    minus the names listed in config['error_file'], label 0 for `<id>_f_...`, 1 otherwise (-1 when not parsed)."""
-    labels, dataset_index, to_remove = {}, [], {}
-    error_file = config.get("error_file", "")
-    if len(error_file) > 0:
-        with open(error_file) as f:
-            for line in f.read().split("\n"):
-                to_remove[line.split(" ")[0]] = True
-    n_meshes = n_rejected = 0
-    for name in sorted(os.listdir(config["root_dir"])):
-        if not name.endswith(".obj"):
-            continue
-        n_meshes += 1
-        if name.split("/").pop() in to_remove:
-            n_rejected += 1
-            continue
-        dataset_index.append(name)
-        labels[name] = (0 if name.split("_")[1] == "f" else 1) if get_sex_from_file_name else -1
-    print("Dataset : {} meshes, {} rejected meshes, {} remaining meshes".format(n_meshes, n_rejected, len(dataset_index)))
+    """-> (dataset_index, labels): what the reference's listMeshes hands to MeshData (data.py:40-72).
+
+    dataset_index = the `*.obj` entries of config['root_dir'] in sorted order, without those whose name is the
+    first blank-separated token of a line of config['error_file'] (empty string = no reject list);
+    labels[name] = 0 when the second `_`-separated field of the name is "f", else 1; -1 for every name when
+    `get_sex_from_file_name` is false."""
+    rejects = set()
+    if config.get("error_file"):
+        with open(config["error_file"]) as fh:
+            rejects = {line.partition(" ")[0] for line in fh.read().split("\n")}
+    found = sorted(e.name for e in os.scandir(config["root_dir"]) if e.name.endswith(".obj"))
+    dataset_index = [n for n in found if n not in rejects]
+
+    def label(name):
+        if not get_sex_from_file_name:
+            return -1
+        return 0 if name.split("_")[1] == "f" else 1
+
+    labels = {n: label(n) for n in dataset_index}
+    print(f"{len(found)} OBJ files under {config['root_dir']}: {len(found) - len(dataset_index)} on the reject list, "
+          f"{len(dataset_index)} kept")
     return dataset_index, labels
 
 
@@ -147,17 +149,20 @@ class DeviceDataset:
     @classmethod
     def from_directory(cls, dataset_index, config, labels, template, dtype="train", device="cuda:0"):
         """MeshData(dataset_index, config, label, template, dtype) (reference data.py:84-200): reads
-        config['root_dir']/<name> for every name that exists, aligns, and handles norm.npz the way the reference does
-        (data.py:166-184): a 'train' split writes config['checkpoint_dir']/norm.npz if it is not there yet, every
-        split then normalises with the file's statistics."""
+        config['root_dir']/<name> for every name that exists, aligns, and hands the statistics over through
+        config['checkpoint_dir']/norm.npz as the reference effectively does (data.py:166-178): its "already there"
+        test looks for a file called `norm`, which np.savez never creates (it appends .npz), so EVERY 'train' split
+        recomputes mean/std from its own meshes and overwrites norm.npz; every split then normalises with the
+        file's current statistics (a later 'test' split sees the last 'train' split's, e.g. per fold of main.py's
+        k-fold loop)."""
         names = [n for n in dataset_index if os.path.exists(os.path.join(config["root_dir"], n))]
         meshes = np.stack([mesh_operations.read_obj(os.path.join(config["root_dir"], n))[0] for n in names])
         ds = cls(meshes, [labels[n] for n in names], template, norm=None, device=device)
         ds.filename = [os.path.join(config["root_dir"], n) for n in names]
         norm_file = os.path.join(config["checkpoint_dir"], "norm.npz")
-        if not os.path.exists(norm_file) and dtype == "train":
+        if dtype == "train":
             os.makedirs(config["checkpoint_dir"], exist_ok=True)
-            np.savez(os.path.join(config["checkpoint_dir"], "norm"), mean=ds.mean.cpu().numpy(), std=ds.std.cpu().numpy())
+            np.savez(norm_file, mean=ds.mean.cpu().numpy(), std=ds.std.cpu().numpy())
         stats = np.load(norm_file, allow_pickle=True)
         ds.mean = torch.as_tensor(stats["mean"], dtype=torch.float64).to(ds.device).contiguous()
         ds.std = torch.as_tensor(stats["std"], dtype=torch.float64).to(ds.device).contiguous()

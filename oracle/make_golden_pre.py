@@ -3,7 +3,7 @@
 
 TEST INFRASTRUCTURE, build container only.  Calls the unmodified ``utils.procrustes`` of /root/reference
 (utils.py:58-157, the alignment data.py:144 applies to every mesh) on seeded similarity-transformed,
-noisy copies of the tiny icosphere and of the 5k template -- one of them mirrored, since
+noisy copies of the tiny icosphere and of a 4998-vertex procedural torus (tests/meshgen.py) -- one of them mirrored, since
 orthogonal_procrustes admits reflections -- and writes inputs and outputs to tests/golden/procrustes.npz.
 
     python oracle/make_golden_pre.py
@@ -52,8 +52,8 @@ def main():
     out = {}
     tiny = np.load(os.path.join(mg.OUT, "topology_tiny.npz"))["verts"].astype(np.float64)
     run("tiny", tiny, cases(tiny, 4, 1, mirror_at=2), out)
-    t5k = np.load(os.path.join(mg.OUT, "template_5k.npz"))
-    v5k = t5k[[k for k in t5k.files if k.startswith("v")][0]].astype(np.float64)
+    # (the "5k" case is this repo's own 4998-vertex torus, tests/meshgen.py -- not the reference's template asset)
+    v5k = np.load(os.path.join(mg.OUT, "hier_torus5k.npz"))["verts"].astype(np.float64)
     run("5k", v5k, cases(v5k, 2, 2, mirror_at=-1), out)
     np.savez_compressed(os.path.join(mg.OUT, "procrustes.npz"), **out)
     print("procrustes.npz", os.path.getsize(os.path.join(mg.OUT, "procrustes.npz")) // 1024, "KiB")

@@ -26,14 +26,23 @@ def _worker(rank, world, port, out_dir):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from meshvae_hip.engine import FlatParams, shard_range
+    from meshvae_hip.engine import FlatParams, rank_generators, shard_range
     from model import load_topology
     from models.cheb_VAE import cheb_VAE
     D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), "cpu")
-    torch.manual_seed(666)
+    # replicas must not depend on equal seeds: every rank initialises DIFFERENTLY here, rank 0's values win
+    torch.manual_seed(666 + 17 * rank)
     net = cheb_VAE(3, TINY_CFG, D, U, A, nn_)
-    before = {k: v.clone() for k, v in net.state_dict().items()}
     flat = FlatParams(net)
+    mine = flat.param.clone()
+    assert flat.broadcast() is True
+    torch.save(flat.param.clone(), os.path.join(out_dir, f"p{rank}.pt"))
+    assert torch.equal(flat.param, mine) == (rank == 0)
+    # per-rank noise streams (reparameterisation eps on the host generator): seed + rank
+    host_gen, dev_gen = rank_generators(666, rank, "cpu")
+    assert dev_gen is None
+    torch.save(torch.normal(mean=0, std=1, size=(4, 16), generator=host_gen), os.path.join(out_dir, f"eps{rank}.pt"))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
     # re-homing keeps values, names and order; params and grads are views of the flat buffers
     # (every tensor starts on a 256-byte boundary; the padding is zero in both buffers)
     assert flat.n_params == sum(v.numel() for v in before.values()) and flat.numel >= flat.n_params
@@ -66,6 +75,33 @@ def test_flat_gradient_allreduce_world2(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     g0, g1 = (torch.load(os.path.join(str(tmp_path), f"g{r}.pt")) for r in (0, 1))
     assert torch.equal(g0, g1)                      # ranks agree bitwise after the all-reduce
+    p0, p1 = (torch.load(os.path.join(str(tmp_path), f"p{r}.pt")) for r in (0, 1))
+    assert torch.equal(p0, p1)                      # identical parameters after the broadcast from rank 0 ...
+    torch.manual_seed(666)
+    from meshvae_hip.engine import FlatParams
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), "cpu")
+    assert torch.equal(FlatParams(cheb_VAE(3, TINY_CFG, D, U, A, nn_)).param, p0)   # ... namely rank 0's (seed 666)
+    e0, e1 = (torch.load(os.path.join(str(tmp_path), f"eps{r}.pt")) for r in (0, 1))
+    assert not torch.equal(e0, e1)                  # ranks draw different reparameterisation noise
+    assert torch.equal(e0, torch.normal(mean=0, std=1, size=(4, 16), generator=torch.Generator().manual_seed(666)))
+
+
+def test_no_grad_range_covers_dec_lin_1():
+    """The flat-buffer span the fused Adam leaves untouched = dec_lin_1 (weight + bias), which the forward never
+    uses (cheb_VAE.py:165) and torch.optim.Adam therefore never updates (its .grad stays None)."""
+    from meshvae_hip.engine import FlatParams
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), "cpu")
+    net = cheb_VAE(3, TINY_CFG, D, U, A, nn_)
+    flat = FlatParams(net)
+    lo, hi = flat.no_grad_range()
+    iw, ib = flat.names.index("dec_lin_1.weight"), flat.names.index("dec_lin_1.bias")
+    assert lo == flat.offsets[iw] and ib == iw + 1 and hi == flat.offsets[ib + 1]
+    assert hi - lo >= net.dec_lin_1.weight.numel() + net.dec_lin_1.bias.numel()
+    assert FlatParams(torch.nn.Linear(3, 4)).no_grad_range() == (0, 0)
 
 
 def test_shard_range_partitions_the_batch():

@@ -97,6 +97,97 @@ def test_trainstep_micro_batched_chains_equal_one_chain():
     torch.testing.assert_close(params[2], params[1], rtol=1e-4, atol=2e-6)
 
 
+def test_two_rank_emulation_equals_one_large_batch():
+    """Data-parallel arithmetic without a second GPU: "rank 0" and "rank 1" each run forward+backward on their
+    shard of a global batch (engine.shard_range), the flat gradients are SUMMED (what the all-reduce does) and the
+    fused Adam applies them with grad_scale = 1/world -- the result must be the single-rank step on the whole batch
+    (the loss is a per-rank mean over meshes, cheb_VAE.py:342, and the shards are equal)."""
+    from meshvae_hip.engine import TrainStep, shard_range
+    dev = torch.device("cuda:0")
+    G, world = 8, 2
+    x = torch.randn(G, 162, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(G) % 2, 2).to(dev)
+    eps = torch.randn(G, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    net1 = _net(dev, dropout=0.0).train()
+    big = TrainStep(net1, G, lr=1e-3, weight_decay=5e-4, use_graph=False)
+    big.load(x, x, y)
+    big._draw_eps = lambda: big.eps.copy_(eps)
+    big.step()
+    nets = [_net(dev, dropout=0.0).train() for _ in range(world)]
+    ranks = []
+    for r, net in enumerate(nets):
+        lo, hi = shard_range(G, r, world)
+        st = TrainStep(net, hi - lo, lr=1e-3, weight_decay=5e-4, use_graph=False)
+        st.load(x[lo:hi], x[lo:hi], y[lo:hi])
+        st.eps.copy_(eps[lo:hi])
+        st._fwd_bwd()                                  # the rank's local backward
+        ranks.append(st)
+    total = ranks[0].flat.grad + ranks[1].flat.grad    # sum all-reduce
+    for st in ranks:
+        st.flat.grad.copy_(total)
+        st.opt.step(1.0 / world)                       # the 1/world scale lives in the Adam kernel
+    torch.cuda.synchronize()
+    assert torch.equal(ranks[0].flat.param, ranks[1].flat.param)
+    torch.testing.assert_close(ranks[0].flat.param, big.flat.param, rtol=1e-4, atol=2e-6)
+
+
+def test_trainstep_leaves_unused_dec_lin_1_alone():
+    """torch.optim.Adam never touches dec_lin_1 (no gradient: cheb_VAE.py:165); the fused Adam over the flat buffer
+    must not decay it either (coupled weight decay on a zero gradient would shrink it every step)."""
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    net = _net(dev, dropout=0.2).train()
+    w0, b0 = net.dec_lin_1.weight.detach().clone(), net.dec_lin_1.bias.detach().clone()
+    other0 = net.dec_lin_2.weight.detach().clone()
+    step = TrainStep(net, 4, lr=1e-2, weight_decay=5e-2, use_graph=False)
+    x = torch.randn(4, 162, 3, device=dev)
+    step.load(x, x, torch.nn.functional.one_hot(torch.arange(4) % 2, 2).to(dev))
+    for _ in range(5):
+        step.step()
+    torch.cuda.synchronize()
+    assert torch.equal(net.dec_lin_1.weight, w0) and torch.equal(net.dec_lin_1.bias, b0)
+    assert not torch.equal(net.dec_lin_2.weight, other0)
+    lo, hi = step.opt.skip
+    assert float(step.opt.exp_avg[lo:hi].abs().sum()) == 0.0 and float(step.opt.exp_avg_sq[lo:hi].abs().sum()) == 0.0
+
+
+def test_eps_provider_only_serves_its_own_batch_size():
+    """TrainStep's static noise buffer is handed to the module only for the batch size it was built for; another
+    batch size through net(...) draws fresh host noise like the reference (no out-of-bounds read of the buffer)."""
+    from meshvae_hip.engine import TrainStep, _Batch
+    dev = torch.device("cuda:0")
+    net = _net(dev, dropout=0.0).train()
+    step = TrainStep(net, 4, use_graph=False)
+    assert net._eps_provider(4, net.z, dev) is step.eps and net._eps_provider(6, net.z, dev) is None
+    x = torch.randn(6, 162, 3, device=dev)
+    y = torch.nn.functional.one_hot(torch.arange(6) % 2, 2).to(dev)
+    torch.manual_seed(11)
+    z1 = net(_Batch(x), x, y, m_type="train")[3][2].clone()
+    torch.manual_seed(11)
+    z2 = net(_Batch(x), x, y, m_type="train")[3][2].clone()
+    torch.manual_seed(12)
+    z3 = net(_Batch(x), x, y, m_type="train")[3][2].clone()
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)      # noise follows the host generator, B = 6 rows of it
+
+
+def test_trainstep_private_noise_generators():
+    """noise_seed gives the step generators of its own (seed + rank): two steps with the same seed replay the same
+    loss sequence whatever the process-wide generators did in between; different seeds differ."""
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    x = torch.randn(4, 162, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(4) % 2, 2).to(dev)
+    runs = []
+    for seed, junk in ((5, 0), (5, 3), (6, 0)):
+        net = _net(dev, dropout=0.2).train()
+        step = TrainStep(net, 4, use_graph=False, noise_seed=seed)
+        step.load(x, x, y)
+        for _ in range(junk):
+            torch.randn(3), torch.rand(3, device=dev)          # disturb the default generators
+        runs.append([float(step.step()[0]) for _ in range(3)])
+    assert runs[0] == runs[1] and runs[0] != runs[2]
+
+
 def test_flat_grads_equal_plain_autograd():
     from meshvae_hip.engine import FlatParams
     dev = torch.device("cuda:0")

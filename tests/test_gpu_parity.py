@@ -79,11 +79,12 @@ def test_cheb_conv_cases(ops_npz, topotiny_npz):
             torch.testing.assert_close(conv.bias.grad.cpu(), _t(ops_npz[f"{case}_gb"]), rtol=1e-4, atol=1e-4)
 
 
-def test_cheb_conv_cases_generic_pipeline(ops_npz, topotiny_npz, monkeypatch):
+def test_cheb_conv_cases_generic_pipeline(ops_npz, topotiny_npz):
     """The same golden cases through the general (non-LDS) pipeline: the path every template too large
     for one CU's LDS takes (BASELINE configs[3], 20k vertices)."""
-    monkeypatch.setenv("MESHVAE_FORCE_GENERIC", "1")
-    test_cheb_conv_cases(ops_npz, topotiny_npz)
+    from meshvae_hip import debug_switch
+    with debug_switch("force_generic", 1):
+        test_cheb_conv_cases(ops_npz, topotiny_npz)
 
 
 def _grid_mesh_edges(side):
@@ -346,11 +347,12 @@ def test_full_model_train_step_matches_reference(which, model_tiny_npz, model_5k
     print(f"[{which}] worst relative gradient error = {worst:.3e}")
 
 
-def test_full_model_train_step_wide_kernel_shape(model_5k_npz, model_tiny_npz, monkeypatch):
-    """The 512 x 10 shape of the 5k-level conv kernels (MESHVAE_L0_CFG=1; default is 1024 x 5) against the
+def test_full_model_train_step_wide_kernel_shape(model_5k_npz, model_tiny_npz):
+    """The 512 x 10 shape of the 5k-level conv kernels (debug switch l0_wide; default is 1024 x 5) against the
     same reference gradients: both shapes stay correct (a semantically neutral edit once broke only one)."""
-    monkeypatch.setenv("MESHVAE_L0_CFG", "1")
-    test_full_model_train_step_matches_reference("5k", model_tiny_npz, model_5k_npz)
+    from meshvae_hip import debug_switch
+    with debug_switch("l0_wide", 1):
+        test_full_model_train_step_matches_reference("5k", model_tiny_npz, model_5k_npz)
 
 
 def test_train_mode_dropout_statistics_and_determinism():

@@ -98,6 +98,33 @@ def test_device_dataset_batches_bit_exact():
     assert ds.batch([])[0].shape == (0, 162, 3)
 
 
+def test_every_train_split_rewrites_norm_npz(tmp_path, capsys):
+    """data.py:166-173 looks for `norm` (np.savez writes norm.npz), so the reference recomputes and overwrites the
+    statistics for EVERY 'train' split: two train splits in one checkpoint_dir must leave the second one's
+    statistics in norm.npz, and a 'test' split built afterwards normalises with those."""
+    from preprocess import DeviceDataset, list_meshes, save_obj
+    from meshgen import torus_mesh
+    dev = _dev()
+    v, f = torus_mesh(8, 12)
+    g = np.random.default_rng(3)
+    root = tmp_path / "data"
+    root.mkdir()
+    for k in range(12):
+        save_obj(str(root / f"{k:03d}_{'f' if k % 2 else 'm'}_0.obj"), v * (1.0 + 0.1 * k) + g.standard_normal(v.shape) * 0.02, f)
+    cfg = {"root_dir": str(root), "error_file": "", "checkpoint_dir": str(tmp_path / "ckpt")}
+    index, labels = list_meshes(cfg)
+    a = DeviceDataset.from_directory(index[:6], cfg, labels, v, dtype="train", device=dev)
+    first = np.load(tmp_path / "ckpt" / "norm.npz")["mean"].copy()
+    b = DeviceDataset.from_directory(index[6:], cfg, labels, v, dtype="train", device=dev)
+    second = np.load(tmp_path / "ckpt" / "norm.npz")["mean"]
+    assert not np.array_equal(first, second)                                   # overwritten, not kept
+    np.testing.assert_array_equal(second, b.ori_data.mean(0).cpu().numpy())    # ... with the second split's own
+    np.testing.assert_array_equal(a.mean.cpu().numpy(), first)
+    t = DeviceDataset.from_directory(index[:3], cfg, labels, v, dtype="test", device=dev)
+    np.testing.assert_array_equal(t.mean.cpu().numpy(), second)
+    capsys.readouterr()
+
+
 def test_dataset_round_trip_through_postprocess():
     """pre- and post-processing are inverses: de-normalising and un-aligning the network *input* with
     postprocess.reconstruction_error (main.py:88-93) returns the original mesh (fp32 tolerance)."""

@@ -225,7 +225,7 @@ def test_flat_buffer_splits_into_conv_head_and_dense_tail():
 
 
 def test_list_meshes_and_obj_round_trip(tmp_path, capsys):
-    """preprocess.list_meshes mirrors data.py:40-72 (sorted .obj names, error-file filter, sex from the file name)."""
+    """preprocess.list_meshes returns what data.py:40-72 returns (sorted .obj names, error-file filter, sex from the file name)."""
     from mesh_operations import read_obj
     from preprocess import list_meshes, save_obj
     v = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.5, 0.0], [0.25, 0.25, 2.0]])
@@ -238,7 +238,7 @@ def test_list_meshes_and_obj_round_trip(tmp_path, capsys):
     (tmp_path / "bad.lst").write_text("0003_f_1.obj some reason\n")
     index, labels = list_meshes({"root_dir": str(tmp_path), "error_file": str(tmp_path / "bad.lst")})
     assert index == ["0001_f_0.obj", "0002_m_0.obj"] and labels == {"0001_f_0.obj": 0, "0002_m_0.obj": 1}
-    assert "3 meshes, 1 rejected meshes, 2 remaining meshes" in capsys.readouterr().out
+    assert "3 OBJ files" in (msg := capsys.readouterr().out) and "1 on the reject list, 2 kept" in msg
     index, labels = list_meshes({"root_dir": str(tmp_path), "error_file": ""}, get_sex_from_file_name=False)
     assert len(index) == 3 and set(labels.values()) == {-1}
     v2, f2 = read_obj(str(tmp_path / "0001_f_0.obj"))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, CFG_20K, TINY_CFG, state_dict_from
+from conftest import CFG_5K, CFG_20K, TINY_CFG, load_golden, state_dict_from
 from oracle import cheb_oracle as O
 
 
@@ -208,6 +208,44 @@ def test_classifier_oracle_matches_reference(which, cls_tiny_npz, cls_5k_npz, to
     for k in g:
         w = _t(npz[f"grad/{k}"])
         torch.testing.assert_close(g[k], w, rtol=1e-4, atol=1e-5 * max(1.0, float(w.abs().max())))
+
+
+def test_pyg_cheb_conv_standin_is_pinned_by_the_in_tree_operator(topotiny_npz):
+    """cheb_pin.npz = the reference's OWN ChebConv (nn/conv.py:390-521, run unmodified by
+    oracle/make_golden_cls_pin.py) on five shapes incl. K = 1, 2, no bias: refshim.PygChebConv -- the stand-in for
+    torch-geometric's class that generated cls_*.npz -- and the oracle's pyg_cheb_conv must both reproduce its
+    outputs and its autograd gradients, with weight[k] = lins.k.weight^T."""
+    from oracle import refshim
+    pin = load_golden("cheb_pin.npz")
+    for tag in (str(c) for c in pin["cases"]):
+        lvl, B, Cin, Cout, K, has_b = (int(v) for v in pin[f"{tag}/meta"])
+        ei = torch.from_numpy(np.vstack([topotiny_npz[f"A{lvl}_row"], topotiny_npz[f"A{lvl}_col"]]).astype(np.int64))
+        W = _t(pin[f"{tag}/weight"])                                   # in-tree layout [K, Cin, Cout]
+        bias = _t(pin[f"{tag}/bias"]) if has_b else None
+        shim = refshim.PygChebConv(Cin, Cout, K, bias=bool(has_b))
+        with torch.no_grad():
+            for k in range(K):
+                shim.lins[k].weight.copy_(W[k].t())
+            if has_b:
+                shim.bias.copy_(bias)
+        x = _t(pin[f"{tag}/x"]).requires_grad_(True)
+        y = shim(x, ei)
+        assert torch.equal(y.detach(), _t(pin[f"{tag}/y"])), tag        # same arithmetic, same order: bit-equal
+        y.backward(_t(pin[f"{tag}/gy"]))
+        torch.testing.assert_close(x.grad, _t(pin[f"{tag}/gx"]), rtol=1e-5, atol=1e-6, msg=tag)
+        gw = torch.stack([lin.weight.grad.t() for lin in shim.lins])
+        torch.testing.assert_close(gw, _t(pin[f"{tag}/gweight"]), rtol=1e-5, atol=1e-5, msg=tag)
+        if has_b:
+            torch.testing.assert_close(shim.bias.grad, _t(pin[f"{tag}/gbias"]), rtol=1e-5, atol=1e-5, msg=tag)
+        # the oracle's functional restatement (what OracleGCN runs)
+        lw = [W[k].t().contiguous().requires_grad_(True) for k in range(K)]
+        x2 = _t(pin[f"{tag}/x"]).requires_grad_(True)
+        y2 = O.pyg_cheb_conv(x2, ei, lw, bias)
+        torch.testing.assert_close(y2, _t(pin[f"{tag}/y"]), rtol=1e-5, atol=1e-6, msg=tag)
+        y2.backward(_t(pin[f"{tag}/gy"]))
+        torch.testing.assert_close(x2.grad, _t(pin[f"{tag}/gx"]), rtol=1e-5, atol=1e-6, msg=tag)
+        torch.testing.assert_close(torch.stack([w.grad.t() for w in lw]), _t(pin[f"{tag}/gweight"]), rtol=1e-5,
+                                   atol=1e-5, msg=tag)
 
 
 def test_estimate_diff_oracle_matches_reference(cls_5k_npz, model_5k_npz, topo5k_npz):
