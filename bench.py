@@ -5,13 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one train step of models.cheb_VAE on a synthetic batch of 64 meshes per GPU
-(BASELINE.json configs[1]: default.cfg architecture on the 4998-vertex template, K=6, fp32,
-dropout 0.2 on, x ~ N(0,1), x_gt = x as fp64 like main.py): forward, backward, one flat RCCL
-all-reduce of the gradients when N > 1, fused Adam.  Inputs are resident in HBM before the
-timed region.  Weak scaling: 64 meshes per rank.  Prints ONE JSON line on rank 0.
+Default (`--config train5k`): one "step" = one train step of models.cheb_VAE on a synthetic batch of 64 meshes
+per GPU (BASELINE.json configs[1]: default.cfg architecture on the 4998-vertex template, K=6, dropout 0.2 on,
+x ~ N(0,1), x_gt = x as fp64 like main.py): forward, backward, one flat RCCL all-reduce of the gradients when
+N > 1, fused Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: 64 meshes per rank.
+Prints ONE JSON line on rank 0.
+
+Other BASELINE configurations, same JSON schema (1 GPU):
+    --config hires20k   configs[3]: 19 992-vertex template, 6 levels, K = 10, train step, 31.2 MB/mesh bound
+    --config infer      configs[4]: crecon.py:170-192 inference path (encode -> classify -> z_mean -> 2 x decode),
+                        hipGraph-captured, latency at batch 1 / 32 / 256 (value = the B = 32 latency)
+    --dtype bf16        configs[1] as worded: activations stored bf16 in HBM, fp32 accumulation (3.90 MB/mesh bound)
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -32,21 +41,36 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-TOPOLOGY = os.path.join(ROOT, "tests", "golden", "topology_5k.npz")
-CFG = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_order": [6, 6, 6, 6, 6],
-       "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
-# module-boundary HBM bytes per mesh, fp32, forward + backward
-ALGO_BYTES_PER_MESH = 7.80e6
-ALGO_FLOP_PER_MESH = 139.4e6
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CFG_5K = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_order": [6, 6, 6, 6, 6],
+          "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
+# BASELINE configs[3] as SURVEY 8(d) pins it: 1->4 subdivision of the 5k template, 6 levels, K = 10
+CFG_20K = {"n_layers": 5, "num_conv_filters": [16, 16, 16, 32, 32, 32], "polygon_order": [10] * 6,
+           "num_classes": 2, "num_style": 16, "num_hidden": 512, "dropout": 0.2}
+CFG = CFG_5K                                  # (older tools import bench.CFG / bench.TOPOLOGY)
+TOPOLOGY = os.path.join(GOLDEN, "topology_5k.npz")
+# module-boundary HBM bytes per mesh, forward + backward
+ALGO_BYTES_PER_MESH = {("train5k", "f32"): 7.80e6, ("train5k", "bf16"): 3.90e6, ("hires20k", "f32"): 31.2e6,
+                       ("hires20k", "bf16"): 15.6e6}
+ALGO_BYTES_FWD_PER_MESH = 2.771e6             # forward only (one encoder + one decoder pass), fp32
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+WORKLOADS = {
+    "train5k": "configs[1]: default.cfg 5k-vertex K=6 ChebConv VAE train step (fwd+bwd+grad all-reduce+Adam), "
+               "dropout 0.2",
+    "hires20k": "configs[3]: 19 992-vertex template (1->4 subdivision of the 5k one), 6 levels, K=10 ChebConv VAE train "
+                "step (fwd+bwd+Adam), dropout 0.2",
+    "infer": "configs[4]: inference path of crecon.py:170-192 on the 5k template (encoder -> classifier -> z_mean -> "
+             "decoder for the predicted and the opposite label), no_grad, hipGraph replay, latency at batch 1/32/256",
+}
 
 
-def build_model(dev):
+def build_model(dev, config="train5k"):
     from model import load_topology
     from models.cheb_VAE import cheb_VAE
-    D, U, A, nn_ = load_topology(TOPOLOGY, dev)
+    hires = config == "hires20k"
+    D, U, A, nn_ = load_topology(os.path.join(GOLDEN, "topology_20k.npz" if hires else "topology_5k.npz"), dev)
     torch.manual_seed(666)
-    return cheb_VAE(3, CFG, D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
+    return cheb_VAE(3, dict(CFG_20K if hires else CFG_5K), D, U, A, nn_, model="optimal_sigma_VAE").to(dev)
 
 
 def time_kernel(fn, iters=30, warm=5):
@@ -62,68 +86,178 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_rooflines(net, B, dev):
-    """Algorithmic bytes / measured duration of the level-0 (4998-vertex, 16-channel) kernels.
-    Algorithmic bytes = every operand of the launch read or written exactly once (DESIGN.md 5);
-    durations are HIP-event averages on the launching stream.  Each op below is one dominant
-    kernel plus a <= 5 us helper launch (weight packing / partial-sum reduce), named in the key."""
+# ----------------------------------------------------------------------------------------------------------------------
+# per-kernel roofline: every ChebConv launch of the model, timed live in isolation through the C ABI
+def source_sha():
+    """Hash of the kernel sources a profile under profiles/ was taken on (tools/pmc_fold.py writes the same hash
+    into <tag>_pmc.json): profile figures are only quoted when they describe the kernels being benchmarked."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mesh-vae_amd", "csrc", "*.h*")) +
+                    [os.path.join(ROOT, "include", "meshvae_hip.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def matching_profile(config="train5k", dtype="f32"):
+    """(tag, pmc table, {kernel: (calls, total_us, avg_us)}) of the newest profiles/*_pmc.json taken on these
+    sources with this bench configuration, or (None, {}, {})."""
+    sha = source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("_src_sha") != sha or d.get("_config", "train5k") != config or d.get("_dtype", "f32") != dtype:
+            continue
+        tag = d.get("_tag") or os.path.basename(path)[:-len("_pmc.json")]
+        stats = {}
+        try:
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))):
+                if r["kernel"] != "TOTAL":
+                    stats[r["kernel"]] = (int(r["calls"]), float(r["total_us"]), float(r["avg_us"]))
+        except (OSError, KeyError, ValueError):
+            pass
+        return tag, d.get("kernels", {}), stats
+    return None, {}, {}
+
+
+def lds_kernel_name(kind, lap, N, Cin, Cout):
+    """Template instance the launchers of csrc/cheb_lds.hip / cheb_dw_lds.hip pick for a layer (mirrors
+    try_cheb_lds / try_cheb_dw_lds), or None when the layer takes another path (split path, stack pipeline)."""
+    pw = 8 if lap.fwd.ell_pairs > 4 else 4
+    if N + 1 > 5120 or lap.fwd.ell_pairs <= 0:
+        return None
+    if 0 < lap.fwd.struct.n_active and 4 * lap.fwd.struct.n_active <= N:
+        return None                                                      # mostly-isolated Laplacian: split path
+
+    def shape(cq, dw):
+        if N + 1 <= 1024:
+            return 1, 0
+        if N + 1 <= 2048:
+            return 2, 0
+        if cq <= 16:
+            return (10, 512) if dw else (5, 1024)
+        return None
+    if kind == "dW":
+        cp, cq = (Cin, Cout) if Cin <= Cout else (Cout, Cin)
+        if cq not in (8, 16, 32):
+            return None
+        s = shape(cq, True)
+        if s is None:
+            return None
+        if (cp + 3) // 4 == 1:
+            cq = 4                                                       # Q-split
+        return f"k_cheb_dw_lds<{cq},{s[0]},{s[1]},{pw}>"
+    cq = Cin if kind == "fwd" else Cout
+    if cq not in (3, 8, 16, 32):
+        return None
+    s = shape(cq, False)
+    if s is None:
+        return None
+    return f"k_cheb_lds<{cq},{s[0]},{s[1]},{pw},{'true' if kind == 'dX' else 'false'}>"
+
+
+def conv_ops(net, B, dev):
+    """One entry per (conv layer, fwd | dX | dW) of the model: a closure that launches it through the C ABI as the
+    public fused-ReLU ops do, its algorithmic bytes (every operand read or written exactly once: DESIGN.md 4) and
+    the name of the kernel instance that dominates it."""
     from meshvae_hip import check, lib
-    from meshvae_hip.functional import workspace
     L = lib()
     net._prepare()
-    lap = net._lap[0]
-    N, C, K, Cout = net.num_nodes[0], 16, 6, 16
+    n = net.n_layers
+    f = net.filters
+    layers = []                                  # (label, lap, N, Cin, Cout, K, relu, has_dx)
+    for i in range(n):
+        layers.append((f"enc{i}", net._lap[i], net.num_nodes[i], f[i], f[i + 1], net.K[i], True, i > 0))
+    for i in range(n):
+        lvl = n - i - 1
+        layers.append((f"dec{i}", net._lap[lvl], net.num_nodes[lvl], f[n + 1 - i], f[n - i], net.K[i], True, True))
+    layers.append(("final", net._lap_final, net.num_nodes[0], f[1], f[0], net.K[n], False, True))
     st = torch.cuda.current_stream(dev).cuda_stream
-    plane = B * N * C * 4                                   # bytes of one [B, N, 16] fp32 tensor
-    x = torch.randn(B, N, C, device=dev)
-    out = torch.empty(B, N, Cout, device=dev)
-    signs = torch.empty(B, N, Cout // 4, dtype=torch.uint8, device=dev)
-    dout = torch.randn(B, N, Cout, device=dev)
-    W = torch.randn(K, C, Cout, device=dev) * 0.1
-    bias = torch.zeros(Cout, device=dev)
-    dW, db, dx = torch.empty_like(W), torch.empty_like(bias), torch.empty_like(x)
-    ws_b = L.mvh_cheb_conv_bwd_ws_bytes(B, N, C, Cout, K)
-    ws = workspace(ws_b, dev)
-    res = {}
-    sign_bytes = B * N * (Cout // 4)
+    ops = []
+    ws_b = max(max(L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K))
+               for _, _, N, Cin, Cout, K, _, _ in layers)
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)   # one scratch buffer: the ops run one after the other
+    for label, lap, N, Cin, Cout, K, relu, has_dx in layers:
+        x = torch.randn(B, N, Cin, device=dev)
+        out = torch.empty(B, N, Cout, device=dev)
+        dout = torch.randn(B, N, Cout, device=dev)
+        W = torch.randn(K, Cin, Cout, device=dev) * 0.1
+        bias = torch.zeros(Cout, device=dev) if relu else None
+        dW, dx = torch.empty_like(W), torch.empty_like(x)
+        db = torch.empty(Cout, device=dev) if relu else None
+        use_signs = relu and Cout % 4 == 0 and K > 1
+        signs = torch.empty(B, N, max(Cout // 4, 1), dtype=torch.uint8, device=dev)
+        keep = (x, out, dout, W, bias, dW, dx, db, signs, ws)
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
-    # the ops exactly as the train step runs them: fused ReLU with its signs kept as bytes
-    def fwd():
-        check(L.mvh_cheb_conv_fwd_signs(st, lap.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                        signs.data_ptr(), B, N, C, Cout, K, ws.data_ptr(), ws_b))
-    res["k_cheb_lds<16,5,1024,4,false> (+k_pack_w): conv+relu fwd L0 16->16"] = dict(
-        ms=time_kernel(fwd), bytes=2 * plane + sign_bytes, launches_per_step=1)      # read x; write out, signs
+        def fwd(lap=lap, x=x, W=W, bias=bias, out=out, signs=signs, N=N, Cin=Cin, Cout=Cout, K=K, ws=ws, ws_b=ws_b,
+                use_signs=use_signs, relu=relu):
+            if use_signs:
+                check(L.mvh_cheb_conv_fwd_signs(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(signs), B, N, Cin, Cout,
+                                                K, p(ws), ws_b))
+            else:
+                check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), None, B, N, Cin, Cout, K,
+                                          int(relu), p(ws), ws_b))
 
-    def bwd_dw():
-        check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                        signs.data_ptr(), dout.data_ptr(), None, dW.data_ptr(), db.data_ptr(),
-                                        B, N, C, Cout, K, ws.data_ptr(), ws_b))
-    res["k_cheb_dw_lds<16,10,512,4> (+k_dw_reduce): conv dW/db L0 16->16"] = dict(
-        ms=time_kernel(bwd_dw), bytes=2 * plane + sign_bytes, launches_per_step=1)   # read x, dout, relu signs
-
-    def bwd_dx():
-        check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(),
-                                        signs.data_ptr(), dout.data_ptr(), dx.data_ptr(), None, None,
-                                        B, N, C, Cout, K, ws.data_ptr(), ws_b))
-    res["k_cheb_lds<16,5,1024,4,true> (+k_pack_w): conv dX L0 16->16"] = dict(
-        ms=time_kernel(bwd_dx), bytes=2 * plane + sign_bytes, launches_per_step=1)   # read dout, signs; write dx
-    return res
-
-
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the named kernel from the committed PMC passes (profiles/): rocprofv3
-    cannot be driven from inside this process, so the counters are collected separately and read here."""
-    path = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic.json")
-    try:
-        table = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for k, v in table.items():
-        if kernel_key.replace(" ", "").startswith(k.replace(" ", "")):
-            return v.get("hbm_bytes")
-    return None
+        def bwd(want_dx, want_dw, lap=lap, x=x, W=W, out=out, signs=signs, dout=dout, dx=dx, dW=dW, db=db, N=N, Cin=Cin,
+                Cout=Cout, K=K, ws=ws, ws_b=ws_b, use_signs=use_signs, relu=relu):
+            a_dx, a_dw, a_db = (p(dx) if want_dx else None), (p(dW) if want_dw else None), (p(db) if want_dw else None)
+            if use_signs:
+                check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(signs), p(dout), a_dx,
+                                                a_dw, a_db, B, N, Cin, Cout, K, p(ws), ws_b))
+            else:
+                check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(dout), None, a_dx, a_dw,
+                                          a_db, B, N, Cin, Cout, K, int(relu), p(ws), ws_b))
+        fwd()                                    # forward once: valid `out` / signs for the backward closures
+        pin, pout = B * N * Cin * 4, B * N * Cout * 4
+        sb = B * N * (Cout // 4) if use_signs else (pout if relu else 0)      # ReLU mask: sign bytes, else the fp32 output
+        desc = f"{label} N={N} {Cin}->{Cout} K={K}"
+        ops.append(dict(op=f"conv fwd {desc}", kernel=lds_kernel_name("fwd", lap, N, Cin, Cout), fn=fwd,
+                        bytes=pin + pout + (B * N * (Cout // 4) if use_signs else 0), keep=keep))
+        if has_dx:
+            ops.append(dict(op=f"conv dX {desc}", kernel=lds_kernel_name("dX", lap, N, Cin, Cout),
+                            fn=lambda bwd=bwd: bwd(True, False), bytes=pout + sb + pin, keep=keep))
+        ops.append(dict(op=f"conv dW {desc}", kernel=lds_kernel_name("dW", lap, N, Cin, Cout),
+                        fn=lambda bwd=bwd: bwd(False, True), bytes=pin + pout + sb, keep=keep))
+    return ops
 
 
+def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "dX", "dW")):
+    """The `roofline` object of the bench line: the conv launch that costs the step most, by the rocprofv3 total-time
+    ranking of the committed profile taken on these sources when there is one (profiles/<tag>_kernel_stats.csv),
+    otherwise by the live isolated timings; `achieved` always comes from the live HIP-event average."""
+    ops = [o for o in conv_ops(net, B, dev) if o["op"].split()[1] in kinds]
+    for o in ops:
+        o["ms"] = time_kernel(o["fn"])
+    tag, pmc, stats = matching_profile(config, dtype)
+    ranking = "live isolated HIP-event timings (no profile of these sources under profiles/)"
+    top = max(ops, key=lambda o: o["ms"])
+    if stats:
+        named = {}
+        for o in ops:
+            if o["kernel"]:
+                named.setdefault(o["kernel"], []).append(o)
+        for kname, _ in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+            if kname in named:
+                top = max(named[kname], key=lambda o: o["ms"])
+                ranking = f"rocprofv3 total time, profiles/{tag}_kernel_stats.csv"
+                break
+    ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+    prof = pmc.get(top["kernel"] or "", {})
+    out = {"bound": "hbm", "kernel": f'{top["kernel"] or "split/stack path"}: {top["op"]}', "achieved": ach,
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": prof.get("hbm_bytes"),
+           "avg_launch_us": top["ms"] * 1e3, "algorithmic_bytes_per_launch": top["bytes"], "ranking": ranking}
+    if prof:
+        out["profile"] = {"tag": tag, "mfma_util": prof.get("mfma_util"), "lds_conflict_frac": prof.get("lds_conflict_frac"),
+                          "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"),
+                          "rocprof_avg_us": stats.get(top["kernel"], (0, 0, None))[2]}
+    table = {o["op"]: {"kernel": o["kernel"], "avg_us": round(o["ms"] * 1e3, 2),
+                       "algo_GBps": round(o["bytes"] / (o["ms"] * 1e-3) / 1e9, 1)} for o in ops}
+    return out, table
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def host_cores():
     """CPUs this process may actually use: min(affinity, cgroup quota) -- the GPU box exposes
     256 hardware threads but caps the container at 16."""
@@ -137,31 +271,119 @@ def host_cores():
     return n
 
 
-def cpu_baseline(B, steps):
-    """The CPU oracle (a port of the reference dataflow) timed on this box's host cores."""
+def cpu_baseline(config, B, budget_s=20.0):
+    """The CPU oracle (a port of the reference dataflow) timed on this box's host cores, on a bounded sample of the
+    same workload: steps are repeated until ~budget_s seconds of CPU work have been spent (at least 2)."""
     from oracle import cheb_oracle as O
     n_threads = host_cores()
     torch.set_num_threads(n_threads)
-    topo = O.Topology(np.load(TOPOLOGY))
+    hires = config == "hires20k"
+    cfg = CFG_20K if hires else CFG_5K
+    topo = O.Topology(np.load(os.path.join(GOLDEN, "topology_20k.npz" if hires else "topology_5k.npz")))
     torch.manual_seed(666)
-    sd = O.init_state_dict(CFG, topo)
-    net = O.OracleVAE(CFG, topo, sd, requires_grad=True)
-    net.training = True
-    x = torch.randn(B, 4998, 3, generator=torch.Generator().manual_seed(0))
+    sd = O.init_state_dict(cfg, topo)
+    train = config != "infer"
+    net = O.OracleVAE(cfg, topo, sd, requires_grad=train)
+    net.training = train
+    n0 = int(topo.num_nodes[0])
+    x = torch.randn(B, n0, 3, generator=torch.Generator().manual_seed(0))
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
 
     def step():
-        for p in net.p.values():
-            p.grad = None
-        net.forward(x, x.double(), y, "train")[0].backward()
+        if train:
+            for p in net.p.values():
+                p.grad = None
+            net.forward(x, x.double(), y, "train")[0].backward()
+        else:                                    # the forward passes of crecon.py:170-192: 1 encoder + 2 decoders
+            with torch.no_grad():
+                net.forward(x, x, y, "test")     # encoder + heads + decoder + loss
+                net.forward(x, x, 1 - y, "test")  # (second decode; its encoder pass makes the sample an upper bound)
     step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 64):
         step()
+        n += 1
     dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "meshes/s", "cores": n_threads, "kind": "port",
-            "sample": f"{steps} train steps (fwd+bwd) of B={B} on the same 5k model after 1 warm-up step, "
-                      f"torch {torch.__version__} CPU, {n_threads} threads"}
+    what = "train steps (fwd+bwd)" if train else "inference passes (2 x full eval forward: >= encode + 2 x decode)"
+    return {"value": B * n / dt, "unit": "meshes/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n} {what} of B={B} on the same model after 1 warm-up, torch {torch.__version__} CPU, "
+                      f"{n_threads} threads, {dt:.1f} s"}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def estimate_diff_fn(net):
+    """The VAE half of crecon.estimate_diff (crecon.py:170-192) over the drop-in module API."""
+    def run(x):
+        h = net.encoder(x)
+        y_hat = net.classifier(h)
+        y = torch.nn.functional.one_hot(y_hat.argmax(-1), 2).to(torch.float32)
+        mu = net.z_mean(torch.cat([y, h], -1))
+        return net.sample(y, mu), net.sample(1.0 - y, mu), y_hat
+    return run
+
+
+def capture_inference(fn, x, dev):
+    """hipGraph of fn(x) (static input buffer x): -> (graph, outputs of the captured call)."""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                # warm the workspaces of the capture stream
+        for _ in range(3):
+            fn(x)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn(x)
+    return g, out
+
+
+def run_infer(args, dev, emit):
+    """BASELINE configs[4]: hipGraph-captured inference latency at B = 1 / 32 / 256 through the reference-API module."""
+    net = build_model(dev).eval()
+    fn = estimate_diff_fn(net)
+    lat, eager = {}, {}
+    iters = max(args.steps, 20)
+    for B in (1, 32, 256):
+        x = torch.randn(B, 4998, 3, device=dev)
+        with torch.no_grad():
+            for _ in range(max(args.warmup, 3)):
+                ref = fn(x)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn(x)
+            torch.cuda.synchronize(dev)
+            eager[B] = (time.perf_counter() - t0) / iters * 1e3
+            g, out = capture_inference(fn, x, dev)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), "hipGraph replay differs from the eager result"
+            for _ in range(max(args.warmup, 3)):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            lat[B] = (time.perf_counter() - t0) / iters * 1e3
+    out = {"metric": "inference latency (encode + classify + 2 x decode, hipGraph replay), 5k-vertex ChebConv VAE, batch 32",
+           "value": lat[32], "unit": "ms", "n_gpus": 1, "steps": iters, "warmup": max(args.warmup, 3),
+           "ms_per_step": lat[32], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "config": {"workload": WORKLOADS["infer"], "vertices": 4998, "hipgraph": True,
+                                           "replay_equals_eager_bitwise": True},
+           "latency_ms": {f"b{b}": lat[b] for b in lat}, "eager_latency_ms": {f"b{b}": eager[b] for b in eager},
+           "meshes_per_s": {f"b{b}": b / lat[b] * 1e3 for b in lat}}
+    # one inference = 1 encoder + 2 decoder passes: ~1.5 x the forward's module-boundary bytes
+    bytes_per_mesh = 1.5 * ALGO_BYTES_FWD_PER_MESH
+    ach = 256 / lat[256] * 1e3 * bytes_per_mesh / 1e9
+    out["step_roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "note": "B = 256 replay: meshes/s x 1.5 x 2.77 MB/mesh (encoder + two decoder passes)"}
+    if not args.no_kernel_roofline:
+        out["roofline"], out["kernels"] = kernel_roofline(net, 256, dev, "infer", kinds=("fwd",))
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline("infer", 32)
+    emit(out)
 
 
 def main():
@@ -169,6 +391,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="train5k")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the activations between layers (arithmetic accumulates in fp32 either way)")
     ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (default: eager C++ launch sequence -- on ROCm 7.2 the "
@@ -177,8 +402,8 @@ def main():
     ap.add_argument("--micro", type=int, default=1, help="independent chains the per-GPU batch is pipelined over")
     ap.add_argument("--prewarm-steps", type=int, default=600,
                     help="untimed steps run BEFORE the --warmup steps (clock / power-state ramp of a cold GPU: the "
-                         "first process on a fresh box was seen 25 %% slow otherwise).  A step COUNT, not a duration: "
-                         "every rank must issue the same number of gradient all-reduces.  0 disables")
+                         "first process on a fresh box was seen 25 %% slow otherwise); reported as prewarm_steps.  A step "
+                         "COUNT, not a duration: every rank must issue the same number of gradient all-reduces.  0 disables")
     ap.add_argument("--rehearse-allreduce", action="store_true",
                     help="1 GPU: bring up a 1-rank RCCL group and run the gradient collective anyway (rehearsal of the "
                          "multi-GPU stream hand-over on a one-GPU box)")
@@ -194,6 +419,10 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,17 +436,23 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.config == "infer":
+        assert world == 1, "--config infer is a single-GPU latency measurement"
+        assert args.dtype == "f32", "--config infer runs the fp32 module path"
+        return run_infer(args, dev, emit)
+
     from meshvae_hip.engine import TrainStep
-    net = build_model(dev)
+    net = build_model(dev, args.config)
     net.train()
     B = args.batch
+    n0 = net.num_nodes[0]
     # weights: same seed on every rank AND a broadcast from rank 0 inside TrainStep; reparameterisation noise and
     # dropout masks: private generators seeded seed + rank, so no two ranks draw the same noise for their shards
     step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=bool(args.graph), m_type="train",
                      n_micro=args.micro, noise_seed=args.seed, rehearse_allreduce=args.rehearse_allreduce,
-                     overlap_allreduce=args.ar_overlap)
+                     overlap_allreduce=args.ar_overlap, storage=args.dtype)
     g = torch.Generator().manual_seed(rank)
-    x = torch.randn(B, 4998, 3, generator=g)
+    x = torch.randn(B, n0, 3, generator=g)
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
     step.x.copy_(x)
     step.x_gt = x.double().to(dev)                   # fp64 ground truth, as main.py:69-70 hands it over
@@ -230,7 +465,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(max(args.prewarm_steps, 0)):   # not part of the contract's W warm-up steps: extra untimed work
+    prewarm = max(args.prewarm_steps, 0) if args.config == "train5k" else min(max(args.prewarm_steps, 0), 60)
+    for i in range(prewarm):   # not part of the contract's W warm-up steps: extra untimed work, reported as prewarm_steps
         step.step()
         if i % 50 == 49:
             torch.cuda.synchronize(dev)
@@ -251,39 +487,33 @@ def main():
 
     if rank == 0:
         meshes_per_s = world * B * args.steps / dt
+        bytes_per_mesh = ALGO_BYTES_PER_MESH[(args.config, args.dtype)]
+        precision = ("fp32 storage and arithmetic (the reference's dtype; --dtype bf16 is configs[1] as worded)"
+                     if args.dtype == "f32" else
+                     "activations and their gradients stored bf16 in HBM between layers, fp32 master weights and fp32 "
+                     "accumulation everywhere (fp32 recurrence state in LDS)")
         out = {
-            "metric": "meshes/sec fwd+bwd, 5k-vertex ChebConv VAE",
+            "metric": "meshes/sec fwd+bwd, 5k-vertex ChebConv VAE" if args.config == "train5k" else
+                      "meshes/sec fwd+bwd, 20k-vertex K=10 ChebConv VAE",
             "value": meshes_per_s, "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "prewarm_steps": max(args.prewarm_steps, 0),
+            "warmup": args.warmup, "prewarm_steps": prewarm,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: default.cfg 5k-vertex K=6 ChebConv VAE train step "
-                                   "(fwd+bwd+grad all-reduce+Adam), 64 meshes/GPU, fp32, dropout 0.2",
-                       "global_batch": world * B, "per_gpu_batch": B, "vertices": 4998,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config] + f", {B} meshes/GPU, {args.dtype} storage",
+                       "global_batch": world * B, "per_gpu_batch": B, "vertices": n0,
                        "parallelism": f"dp{world}", "hipgraph": bool(step.use_graph),
-                       "micro_batches": step.n_micro,
-                       "precision": "fp32 storage and arithmetic: configs[1] names bf16 storage, this run keeps the "
-                                    "reference's fp32 (the higher precision, and the one the 1e-4 parity bar is stated in)"},
-            "step_roofline": {"bound": "hbm", "achieved": meshes_per_s / world * ALGO_BYTES_PER_MESH / 1e9,
+                       "micro_batches": step.n_micro, "precision": precision},
+            "step_roofline": {"bound": "hbm", "achieved": meshes_per_s / world * bytes_per_mesh / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": meshes_per_s / world * ALGO_BYTES_PER_MESH / 1e9 / HBM_PEAK_GBS,
-                              "note": "whole step per GPU: meshes/s x 7.80 MB/mesh (SURVEY 8(d))"},
+                              "frac": meshes_per_s / world * bytes_per_mesh / 1e9 / HBM_PEAK_GBS,
+                              "note": f"whole step per GPU: meshes/s x {bytes_per_mesh / 1e6:.2f} MB/mesh (SURVEY 8(d))"},
             "final_loss": loss,
         }
         if not args.no_kernel_roofline:
-            ks = kernel_rooflines(net, B, dev)
-            name = max((k for k in ks if k.startswith("k_")), key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
-            # (the dominant kernel of the step by total time: see profiles/ for the rocprofv3 view)
-            d = ks[name]
-            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name),
-                               "avg_launch_us": d["ms"] * 1e3, "algorithmic_bytes_per_launch": d["bytes"]}
-            out["kernels"] = {k: {"avg_ms": v["ms"], "algo_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
+            out["roofline"], out["kernels"] = kernel_roofline(net, B, dev, args.config, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, 8)   # ~10-20 s of CPU work on 16 cores
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+            out["cpu_baseline"] = cpu_baseline(args.config, B if args.config == "train5k" else 4)
+        emit(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

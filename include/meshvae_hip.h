@@ -269,7 +269,9 @@ int mvh_gather_normalize(mvh_stream_t stream, const double* data, int64_t n_mesh
  * drop_u [B*(3H + flat)] uniforms for the four dropout sites in order (encoder h, classifier,
  * dec_lin, dec_lin_2), NULL = eval.  Activations and their gradients live in `ws`
  * (mvh_vae_step_ws_bytes), which must be passed unchanged from forward to backward.
- * backward overwrites every gradient (dec_lin_1: zeros); its weight-gradient kernels run on
+ * backward overwrites every gradient except dec_lin_1's, which it never touches (the forward never uses
+ * that layer, cheb_VAE.py:165, so torch leaves its .grad None: hand in zeros if the span is all-reduced
+ * with the rest, and skip it in the optimizer, mvh_adam_step); its weight-gradient kernels run on
  * internal side streams forked from and joined to `stream` with events (hipGraph-capturable).
  * d_loss: device scalar (dtype of the loss) scaling every gradient, or NULL = 1: the forward
  * already leaves the d_loss = 1 gradient seeds of the loss in `ws`, so NULL costs no launch. */

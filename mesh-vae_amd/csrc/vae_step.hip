@@ -146,12 +146,6 @@ struct SideStream {
   bool dense_recorded = false;
 };
 
-// (a kernel rather than hipMemsetAsync: memset nodes on a forked stream crashed graph instantiation)
-__global__ void __launch_bounds__(256) k_zero(float* __restrict__ p, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0.f;
-}
-
 // Per host thread: the step engine may be driven by several enqueue threads (one per chain of
 // meshes, engine.py TrainStep n_micro > 1); each gets its own side stream and event ring.
 static SideStream* side_for_device() {
@@ -466,11 +460,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                          G[ix.zmB()], G[ix.zvW()], G[ix.zvB()], B, p.H, p.C, p.Z));
     TRY(mvh_linear_bwd(ds, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), nullptr, G[ix.encLW()], G[ix.encLB()], B,
                        p.flat, p.H, MVH_ACT_RELU, pd, nullptr, 0));
-    // dec_lin_1 is never used by the forward (cheb_VAE.py:165): zero gradient
-    hipLaunchKernelGGL(k_zero, dim3(cdiv((long long)p.H * (p.C + p.Z), 256)), dim3(256), 0, dstream, G[ix.dl1W()],
-                       (long long)p.H * (p.C + p.Z));
-    hipLaunchKernelGGL(k_zero, dim3(cdiv(p.H, 256)), dim3(256), 0, dstream, G[ix.dl1B()], (long long)p.H);
-    MVH_LAUNCH_CHECK();
+    // dec_lin_1 is never used by the forward (cheb_VAE.py:165): it HAS no gradient (torch leaves .grad None and
+    // Adam skips it), so G[dl1W] / G[dl1B] are not written -- the engine's flat buffer keeps its zeros there
     // every dense-layer gradient (98 % of the parameter bytes) is final from here on: a data-parallel caller
     // starts their all-reduce now, under the encoder half of the backward (mvh_vae_wait_dense_grads).
     // Not inside a stream capture: the event would become part of the graph.

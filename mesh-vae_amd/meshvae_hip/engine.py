@@ -175,12 +175,20 @@ class TrainStep:
     """
 
     def __init__(self, net, batch, lr=1e-3, weight_decay=5e-4, use_graph=True, m_type="train", group=None,
-                 native=True, n_micro=1, noise_seed=None, rehearse_allreduce=False, overlap_allreduce=False):
+                 native=True, n_micro=1, noise_seed=None, rehearse_allreduce=False, overlap_allreduce=False,
+                 storage="f32"):
         """noise_seed: reparameterisation noise and dropout uniforms come from generators private to this step,
         seeded `noise_seed + rank` (rank_generators).  None on a single rank keeps the reference's behaviour --
         the process-wide default generators (cheb_VAE.py:316) -- and on a multi-rank group means 666.
         rehearse_allreduce: run the gradient collective even on a 1-rank group; overlap_allreduce: the
-        two-bucket form of _all_reduce_overlapped (opt-in until an 8-GPU measurement says otherwise)."""
+        two-bucket form of _all_reduce_overlapped (opt-in until an 8-GPU measurement says otherwise).
+        storage: "f32" (the reference's dtype) or "bf16": activations and their gradients between the conv layers
+        are stored bf16 in HBM, arithmetic accumulates in fp32 (BASELINE configs[1] as worded; native step only)."""
+        if storage not in ("f32", "bf16"):
+            raise ValueError("storage must be 'f32' or 'bf16'")
+        if storage == "bf16" and not native:
+            raise ValueError("bf16 storage exists in the native step only")
+        self.storage = storage
         self.net, self.B, self.m_type, self.group = net, batch, m_type, group
         self.dev = next(net.parameters()).device
         self.flat = FlatParams(net)
@@ -232,15 +240,22 @@ class TrainStep:
                 # the ROCm 7.2 runtime tops out at ~340 k launches/s over all host threads (225 k/s on
                 # one), so two chains cost ~0.75 ms of launching and n_micro = 2 is slower (0.97 ms)
                 # than one chain (0.90 ms); n_micro stays 1 by default.  hipGraph capture: single thread, chain 0 forks to a
-                # torch side stream, chains >= 1 keep dW inline (a fork of a fork crashes graph
-                # instantiation on ROCm 7.2, tools/capture_probe.py).
+                # torch side stream, chains >= 1 keep dW inline on their own stream, i.e. no captured stream that joined
+                # the capture through an event ever forks a further stream.  Evidence (tools/graph_diag.py, one run per
+                # scenario, raw HIP API with return codes + faulthandler): on ROCm 7.2 hipStreamEndCapture itself dies
+                # with SIGSEGV -- before any hipGraphInstantiate -- for a nested fork made of three torch streams and
+                # plain torch add kernels (main -> s1 -> s2, every branch joined; no code of this library involved),
+                # and identically for the two-chain train step; single-level forks, also with a memset node on the
+                # forked branch, capture (3 nodes / 2 edges), instantiate and replay with rc 0.  So the limitation is
+                # the runtime's handling of second-level forks, not an unjoined branch or event reuse here; the
+                # supported topology is covered by tests/test_gpu_engine.py::test_trainstep_graph_two_chains.
                 chain = torch.cuda.Stream(self.dev) if j > 0 else None
                 if use_graph:
                     side = chain if j > 0 else torch.cuda.Stream(self.dev)
                 else:
                     side = None
                 self.streams.append((chain, side))
-                self.native.append(NativeStep(net, mb, grads=grads, side_stream=side))
+                self.native.append(NativeStep(net, mb, grads=grads, side_stream=side, storage=storage))
             if self.n_micro > 1 and not use_graph:
                 from concurrent.futures import ThreadPoolExecutor
                 self.pool = ThreadPoolExecutor(max_workers=self.n_micro - 1, thread_name_prefix="meshvae-chain")
@@ -346,6 +361,8 @@ class TrainStep:
             if self.graph_fb is None:
                 self.capture()
             self.graph_fb.replay()
+            if self.n_micro > 1:
+                self._out = None                # assembled from the chains' (static) outputs on the next access
             self.flat.all_reduce(self.group, always=self.rehearse_allreduce)
             self.graph_opt.replay()
             self.opt._host_step = None          # the replay advanced the device-side step counter
@@ -458,9 +475,10 @@ class NativeStep:
     written straight into the module's (flat) .grad views, weight-gradient kernels run on a
     side stream.  Semantics are those of `cheb_VAE.forward(data, x_gt, y, m_type)`."""
 
-    def __init__(self, net, batch, grads=None, side_stream=None):
+    def __init__(self, net, batch, grads=None, side_stream=None, storage="f32"):
         """grads: optional list of gradient tensors (one per parameter, default = the .grad views);
-        side_stream: torch stream for the weight-gradient kernels (default: one internal per device)."""
+        side_stream: torch stream for the weight-gradient kernels (default: one internal per device);
+        storage: "f32" | "bf16" storage of the activations between the conv layers (mvh_vae_desc_t.storage)."""
         import ctypes
         from . import VaeDesc
         self.side = side_stream

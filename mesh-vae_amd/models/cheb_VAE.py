@@ -154,8 +154,8 @@ class cheb_VAE(torch.nn.Module):
         if m_type == "train":
             provider = getattr(self, "_eps_provider", None)
             if provider is not None:       # engine.TrainStep: static device buffer refilled from the host RNG
-                eps = provider(B, self.z, h.device)
-            else:
+                eps = provider(B, self.z, h.device)     # (None for a batch size the buffer was not built for)
+            if eps is None:
                 # drawn on the host default generator, exactly as the reference does (:316)
                 eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(h.device)
         return F_hip.latent_head(h, y.to(torch.float32), self.classifier_layer.weight, self.classifier_layer.bias,
@@ -214,8 +214,9 @@ class cheb_VAE(torch.nn.Module):
         eps = None
         if m_type == "train":
             provider = getattr(self, "_eps_provider", None)
-            eps = provider(B, self.z, dev) if provider is not None else \
-                torch.normal(mean=0, std=1, size=(B, self.z)).to(dev)      # host generator, as the reference (:316)
+            eps = provider(B, self.z, dev) if provider is not None else None
+            if eps is None:                # no engine buffer for this batch size: host generator, as the reference (:316)
+                eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(dev)
         drop_u = torch.rand(B * step.u_cols, device=dev) if (self.training and self.dropout.p > 0.0) else None
         ent["gen"] += 1
         if not torch.is_grad_enabled():              # evaluate loops (main.py:129): the same launch sequence, forward only

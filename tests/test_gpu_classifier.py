@@ -139,6 +139,44 @@ def test_estimate_diff_matches_reference(cls_5k_npz, model_5k_npz):
     assert torch.isfinite(la).all() and torch.isfinite(lb).all() and not torch.equal(la, lb)
 
 
+def test_inference_hipgraph_replay_config4(cls_5k_npz, model_5k_npz):
+    """BASELINE configs[4]: the VAE inference of crecon.py:170-192 (encoder -> classifier -> z_mean -> decoder for the
+    predicted and the opposite label) captured in a hipGraph on the 5k template -- bench.py --config infer's own
+    functions.  Replay == eager bitwise at B = 1 / 32 / 256 (and after the input buffer is refilled), and at the
+    fixture's batch the replayed reconstructions reproduce the reference's `estimate_diff(..., "test")` vectors."""
+    import bench
+    dev = _dev()
+    net = bench.build_model(dev)                       # seed-666 weights = the fixture's state_dict
+    net.load_state_dict(state_dict_from(model_5k_npz))
+    net.eval()
+    fn = bench.estimate_diff_fn(net)
+    with torch.no_grad():
+        for B in (1, 32, 256):
+            g0 = torch.Generator().manual_seed(B)
+            x = torch.randn(B, 4998, 3, generator=g0).to(dev)
+            ref = [t.clone() for t in fn(x)]
+            graph, out = bench.capture_inference(fn, x, dev)
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), B
+            x.copy_(torch.randn(B, 4998, 3, generator=g0))            # new meshes through the same graph
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(out, fn(x)):
+                assert torch.equal(a, b), B
+        # the reference's vectors (oracle/make_golden_cls.py: crecon.estimate_diff on the seed-666 VAE, eval mode, B = 4)
+        x4 = torch.from_numpy(cls_5k_npz["diff/x"]).to(dev)
+        graph, (recon, recon_oppo, y_hat) = bench.capture_inference(fn, x4, dev)
+        graph.replay()
+        torch.cuda.synchronize()
+        diff = torch.cat((x4 - recon_oppo, x4 - recon), dim=-1).cpu()
+        want = torch.from_numpy(cls_5k_npz["diff/test"])
+        assert float((diff - want).abs().max()) < 1e-4, float((diff - want).abs().max())
+        label = torch.from_numpy(cls_5k_npz["diff/label"])
+        assert int((y_hat.argmax(-1).cpu() == label).sum()) == int(cls_5k_npz["diff/test_correct"])
+
+
 def test_classifier_step_graph_equals_eager_and_module_path():
     """engine.ClassifierStep: the hipGraph replay is bitwise equal to the eager launch sequence, and both follow
     the plain module path (estimate_diff -> cheb_GCN -> CrossEntropyLoss -> torch.optim.Adam, crecon.py:65-100)."""

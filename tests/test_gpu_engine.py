@@ -97,6 +97,35 @@ def test_trainstep_micro_batched_chains_equal_one_chain():
     torch.testing.assert_close(params[2], params[1], rtol=1e-4, atol=2e-6)
 
 
+def test_trainstep_graph_two_chains():
+    """The hipGraph topology the engine supports for micro-batched chains (n_micro = 2, use_graph = True): chain 1 is
+    one fork of the capture stream and keeps its weight-gradient kernels inline (a second-level fork kills
+    hipStreamEndCapture on ROCm 7.2, tools/graph_diag.py).  Replay must equal the eager single chain."""
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    B = 8
+    x = torch.randn(B, 162, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    res = {}
+    for mode, n_micro, graph in (("eager1", 1, False), ("graph2", 2, True)):
+        net = _net(dev, dropout=0.0).train()
+        step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=graph, n_micro=n_micro)
+        assert step.n_micro == n_micro
+        step.load(x, x, y)
+        init = step.flat.param.clone()
+        if graph:
+            step.capture(warmup=1)
+        step.flat.param.copy_(init)
+        step.opt.exp_avg.zero_(), step.opt.exp_avg_sq.zero_(), step.opt.step_count.zero_()
+        torch.manual_seed(7)
+        for _ in range(3):
+            step.step()
+        torch.cuda.synchronize()
+        res[mode] = (step.flat.param.clone(), float(step.out[0]))
+    torch.testing.assert_close(res["graph2"][0], res["eager1"][0], rtol=1e-4, atol=2e-6)
+    assert abs(res["graph2"][1] - res["eager1"][1]) <= 1e-5 * abs(res["eager1"][1]) + 1e-3
+
+
 def test_two_rank_emulation_equals_one_large_batch():
     """Data-parallel arithmetic without a second GPU: "rank 0" and "rank 1" each run forward+backward on their
     shard of a global batch (engine.shard_range), the flat gradients are SUMMED (what the all-reduce does) and the
@@ -484,14 +513,12 @@ def test_piecewise_inference_calls_take_the_native_sequences():
     assert h.requires_grad
 
 
-def test_bench_line_contract():
-    """bench.py prints exactly one JSON line on stdout carrying the keys the driver reads, the roofline object of
-    the dominant kernel and the CPU baseline (one child process: the script redirects its own stdout)."""
+def _bench_line(*extra):
     import json
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
-                          "--prewarm-steps", "20"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True,
+                         timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[:500]
@@ -499,13 +526,33 @@ def test_bench_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "meshes/s"
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["vs_baseline"] is None and d["n_gpus"] == 1
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] and r["ranking"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "meshes/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    return d
+
+
+def test_bench_line_contract():
+    """bench.py prints exactly one JSON line on stdout carrying the keys the driver reads, the roofline object of
+    the dominant kernel and the CPU baseline (one child process: the script redirects its own stdout)."""
+    d = _bench_line("--steps", "5", "--warmup", "2", "--prewarm-steps", "20")
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["prewarm_steps"] == 20 and d["unit"] == "meshes/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["config"]["workload"].startswith("configs[1]")
     assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert len(d["kernels"]) == 26                       # 9 conv layers x (fwd, dX, dW) minus the first layer's dX
+
+
+def test_bench_infer_line_contract():
+    """bench.py --config infer (BASELINE configs[4]): the same schema, latency-like (lower is better), with the three
+    hipGraph replay latencies the configuration names."""
+    d = _bench_line("--config", "infer", "--steps", "20", "--warmup", "3")
+    assert d["unit"] == "ms" and d["higher_is_better"] is False and d["config"]["workload"].startswith("configs[4]")
+    assert set(d["latency_ms"]) == {"b1", "b32", "b256"} and d["value"] == d["latency_ms"]["b32"]
+    assert all(0.0 < v < 50.0 for v in d["latency_ms"].values())
+    assert d["config"]["hipgraph"] is True and d["config"]["replay_equals_eager_bitwise"] is True

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold the rocprofv3 output of tools/profile_round.sh into the two tracked evidence files of a round:
 
-    python tools/pmc_fold.py gpurun_out/<tag> <tag> [dst_dir = profiles/]
+    python tools/pmc_fold.py gpurun_out/<tag> <tag> [dst_dir = profiles/] [config = train5k] [dtype = f32]
       -> profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats summary, short kernel names)
       -> profiles/<tag>_pmc.json           (per kernel, averages per dispatch over every PMC pass)
 
@@ -81,9 +81,21 @@ def fold_stats(out_dir, dst):
     return rows
 
 
+def source_sha():
+    """Same hash as bench.source_sha(): bench.py quotes a profile only for the sources it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mesh-vae_amd", "csrc", "*.h*")) +
+                    [os.path.join(ROOT, "include", "meshvae_hip.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
     prof = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
+    config = sys.argv[4] if len(sys.argv) > 4 else "train5k"
+    dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
     os.makedirs(prof, exist_ok=True)
     rows = fold_stats(out_dir, os.path.join(prof, f"{tag}_kernel_stats.csv"))
     pmc = fold_pmc(out_dir)
@@ -94,7 +106,10 @@ def main():
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         pass
-    json.dump({"_how": __doc__.strip(), "_tag": tag, "_head": head, "kernels": keep},
+    sha_file = os.path.join(out_dir, "src_sha.txt")          # written on the GPU box: the sources the run was made on
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else source_sha()
+    json.dump({"_how": __doc__.strip(), "_tag": tag, "_head": head, "_src_sha": sha, "_config": config, "_dtype": dtype,
+               "kernels": keep},
               open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
     bj = os.path.join(out_dir, "bench_n1.json")
     if os.path.exists(bj) and os.path.getsize(bj) > 0:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag> [bench args...]
+#   tools/profile_round.sh <tag> [bench args, e.g. --config hires20k / --dtype bf16 ...]
 # 1. plain bench line                    -> gpurun_out/<tag>/bench_n1.json
 # 2. rocprofv3 --kernel-trace --stats    -> gpurun_out/<tag>/stats/   (program directly after `--`)
 # 3. PMC passes, each in its own run with --kernel-trace only (no --stats-free trace domains):
@@ -10,6 +10,13 @@ set -e -o pipefail
 TAG="$1"; shift
 OUT="gpurun_out/$TAG"
 mkdir -p "$OUT"
+CONFIG=train5k; DTYPE=f32; prev=""
+for a in "$@"; do
+  [ "$prev" = "--config" ] && CONFIG="$a"
+  [ "$prev" = "--dtype" ] && DTYPE="$a"
+  prev="$a"
+done
+python -c "import bench; print(bench.source_sha())" > "$OUT/src_sha.txt"
 export TMPDIR=/tmp
 BENCH_ARGS="$@"
 python bench.py --steps 100 --warmup 20 $BENCH_ARGS > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
@@ -22,4 +29,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONF
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python3 bench.py $SHORT > "$OUT/pmc_$name.log" 2>&1 || echo "pmc $name FAILED (see log)"
   echo "pmc $name done"
 done
-python tools/pmc_fold.py "$OUT" "$TAG" "$OUT"   # (re-run locally to write profiles/)
+python tools/pmc_fold.py "$OUT" "$TAG" "$OUT" "$CONFIG" "$DTYPE"   # (re-run locally with profiles/ as destination)
