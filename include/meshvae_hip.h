@@ -152,6 +152,22 @@ int mvh_cheb_conv_bwd_signs(mvh_stream_t stream, const mvh_csr_t* lap, const mvh
                             int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K,
                             void* ws, size_t ws_bytes);
 
+/* The same two ops on bf16-STORED activations (BASELINE configs[1] "bf16"; reference arithmetic nn/conv.py:557-577):
+ * x, out, dout, dx are [B,N,C] tensors of 2-byte bfloat16 (round-to-nearest-even at every store), W / bias / dW / db
+ * stay fp32 and every sum is accumulated in fp32 (the recurrence state lives in LDS as fp32).  Cin % 4 == Cout % 4 == 0.
+ * act == MVH_ACT_RELU: the forward writes relu_signs [B,N,Cout/4] and the backward reads them (the bf16 output is
+ * not needed again); act == MVH_ACT_NONE: relu_signs may be NULL.  Workspaces as for the fp32 ops.  Only layers the
+ * LDS-resident kernels can take (N + 1 <= 5120 etc.) are supported: others return MVH_ERR_UNSUPPORTED. */
+int mvh_cheb_conv_fwd_bf16(mvh_stream_t stream, const mvh_csr_t* lap, const void* x, const float* W,
+                           const float* bias, void* out, uint8_t* relu_signs,
+                           int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                           void* ws, size_t ws_bytes);
+int mvh_cheb_conv_bwd_bf16(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t,
+                           const void* x, const float* W, const uint8_t* relu_signs, const void* dout,
+                           void* dx, float* dW, float* db,
+                           int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                           void* ws, size_t ws_bytes);
+
 /* ---- rows E/D (dense parts): nn.Linear + F.relu + nn.Dropout (cheb_VAE.py:270-272,277-280).
  * y[B,out] = drop( act( x[B,in] W[out,in]^T + bias ) ); drop keeps element i when
  * drop_u[i] >= p and scales by 1/(1-p); drop_u == NULL or p == 0 disables it. */
@@ -276,9 +292,18 @@ int mvh_gather_normalize(mvh_stream_t stream, const double* data, int64_t n_mesh
  * d_loss: device scalar (dtype of the loss) scaling every gradient, or NULL = 1: the forward
  * already leaves the d_loss = 1 gradient seeds of the loss in `ws`, so NULL costs no launch. */
 #define MVH_VAE_MAX_LAYERS 8
+/* storage of the conv-level activations (and their gradients) between two layers inside `ws`:
+ * MVH_STORAGE_F32 = the reference's dtype (default); MVH_STORAGE_BF16 = BASELINE configs[1] "bf16": 2-byte
+ * tensors in HBM, every kernel converts at its loads / stores, arithmetic and the Chebyshev recurrence state
+ * (LDS) stay fp32, parameters / gradients / Adam state stay fp32.  The network input x, recon, the dense head
+ * and the loss are fp32 in both modes.  bf16 exists on the LDS-resident kernels only: a model with a level
+ * that needs the general stack pipeline (N + 1 > 5120) returns MVH_ERR_UNSUPPORTED. */
+#define MVH_STORAGE_F32 0
+#define MVH_STORAGE_BF16 1
 typedef struct mvh_vae_desc {
   int32_t n_layers, num_features, num_hidden, num_classes, num_style;
   float dropout_p;
+  int32_t storage;
   int32_t filters[MVH_VAE_MAX_LAYERS + 2];
   int32_t K[MVH_VAE_MAX_LAYERS + 1];
   int32_t num_nodes[MVH_VAE_MAX_LAYERS + 1];

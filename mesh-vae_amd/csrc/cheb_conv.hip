@@ -11,6 +11,7 @@
 // Weights are wave-uniform and read through the scalar cache (s_load) so the inner loops are
 // v_fma with an SGPR operand; activations move as 16-byte vectors.
 #include "common.hpp"
+#include "bf16.hpp"
 
 namespace mvh {
 
@@ -19,7 +20,8 @@ template <int COUT_T, bool FULL, bool VIN>
 __global__ void __launch_bounds__(256)
 k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ W,
                 const float* __restrict__ bias, float* __restrict__ out, long long rows, int Cin,
-                int Cout, int K, int act) {
+                int Cout, int K, int act, int x_bf16) {
+  // x_bf16: x is stored as bf16 (K == 1 only: the W_eff pass of the split path; the launcher checks)
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float acc[COUT_T];
@@ -60,7 +62,7 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
     const float* Wk = W + (long long)k * Cin * Cout;
     if constexpr (VIN) {
       for (int c4 = 0; c4 < Cin; c4 += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src + c4);
+        const float4 t = x_bf16 ? load4_any(x, r * Cin + c4, true) : *reinterpret_cast<const float4*>(src + c4);
         const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -98,12 +100,15 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
 
 static int launch_contract(hipStream_t st, const float* x, const float* tx, const float* W,
                            const float* bias, float* out, long long rows, int Cin, int Cout, int K,
-                           int act) {
+                           int act, bool x_bf16 = false) {
   const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
+  if (x_bf16 && (!vin || K != 1 || Cin == 16 && Cout == 16))
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 rows reach the contraction only through the K = 1 split pass");
+  const int xb = x_bf16 ? 1 : 0;
   const int grid = cdiv(rows, 256);
 #define MVH_C(CT, FULL, VIN)                                                                    \
   hipLaunchKernelGGL((k_cheb_contract<CT, FULL, VIN>), dim3(grid), dim3(256), 0, st, x, tx, W,  \
-                     bias, out, rows, Cin, Cout, K, act)
+                     bias, out, rows, Cin, Cout, K, act, xb)
 #define MVH_CV(CT, FULL) \
   do { if (vin) MVH_C(CT, FULL, true); else MVH_C(CT, FULL, false); } while (0)
   if (Cout == 3) MVH_CV(3, true);
@@ -174,7 +179,7 @@ k_cheb_gstack(const float* __restrict__ dout, const float* __restrict__ out, con
 template <int COUT_T>
 __global__ void __launch_bounds__(256)
 k_gstack_rows(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ W,
-              float* __restrict__ g0, long long total, int Cin, int act) {
+              float* __restrict__ g0, long long total, int Cin, int act, int g_bf16) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int QV = Cin >> 2, q = (int)(idx % QV);
@@ -192,7 +197,7 @@ k_gstack_rows(const float* __restrict__ dout, const float* __restrict__ out, con
 #pragma unroll
     for (int t = 0; t < 4; ++t) g[t] = fmaf(d, w[t][co], g[t]);
   }
-  *reinterpret_cast<float4*>(g0 + r * Cin + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
+  store4_any(g0, r * Cin + 4 * q, g_bf16 != 0, g[0], g[1], g[2], g[3]);  // (bf16 storage of the gradient rows)
 }
 
 // 16 -> 16 channels on a big level (the 20k-vertex level of BASELINE configs[3]: 82 MB of dout in, 819 MB of
@@ -240,16 +245,18 @@ k_gstack_mfma16(const float* __restrict__ dout, const float* __restrict__ out, c
 }
 
 static int launch_gstack(hipStream_t st, const float* dout, const float* out, const float* W, float* G,
-                         float* g0, long long rows, int Cin, int Cout, int K, int act) {
+                         float* g0, long long rows, int Cin, int Cout, int K, int act, bool g_bf16 = false) {
   if (K == 1 && (Cin & 3) == 0 && ((uintptr_t)g0 & 15) == 0 && (Cout == 3 || Cout == 4)) {
     const long long total = rows * (Cin >> 2);
+    const int gb = g_bf16 ? 1 : 0;
     if (Cout == 3)
-      hipLaunchKernelGGL((k_gstack_rows<3>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
+      hipLaunchKernelGGL((k_gstack_rows<3>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act, gb);
     else
-      hipLaunchKernelGGL((k_gstack_rows<4>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act);
+      hipLaunchKernelGGL((k_gstack_rows<4>), dim3(cdiv(total, 256)), dim3(256), 0, st, dout, out, W, g0, total, Cin, act, gb);
     MVH_LAUNCH_CHECK();
     return MVH_OK;
   }
+  if (g_bf16) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 gradient rows leave the G-stack only through the K = 1 split pass");
   if (Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !dbg().no_gstack_mfma &&
       (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)W | (uintptr_t)G | (uintptr_t)g0) & 15) == 0) {
     const long long nblk = (rows + 15) / 16;
@@ -588,7 +595,7 @@ constexpr int kXtyGrid = 1024;
 template <int CD>
 __global__ void __launch_bounds__(256)
 k_xty_small(const float* __restrict__ x, const float* __restrict__ d, float* __restrict__ partial, long long rows,
-            int CX) {
+            int CX, int x_bf16) {
   const int QV = CX >> 2, RPW = 64 / QV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane % QV, rsub = lane / QV;
@@ -602,7 +609,7 @@ k_xty_small(const float* __restrict__ x, const float* __restrict__ d, float* __r
   const long long stride = (long long)gridDim.x * 4 * RPW;
 #pragma unroll 4
   for (long long r = ((long long)blockIdx.x * 4 + wave) * RPW + rsub; r < rows; r += stride) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * CX + 4 * q);
+    const float4 xv = load4_any(x, r * CX + 4 * q, x_bf16 != 0);  // (wave-uniform select, one load per trip)
     float dv[CD];
 #pragma unroll
     for (int c = 0; c < CD; ++c) dv[c] = d[r * CD + c];
@@ -663,7 +670,7 @@ k_xty_finish(const float* __restrict__ partial, int nblocks, int nout, int n_s, 
 
 // *handled == false: not eligible (caller keeps the LDS-kernel K = 1 pass)
 static int try_xty_small(hipStream_t st, const float* x, const float* dpre, float* S, float* db, long long rows,
-                         int Cin, int Cout, float* partial, size_t part_bytes, bool* handled) {
+                         int Cin, int Cout, float* partial, size_t part_bytes, bool* handled, bool x_bf16 = false) {
   *handled = false;
   if ((Cout != 3 && Cout != 4) || (Cin != 8 && Cin != 16 && Cin != 32)) return MVH_OK;
   if (((uintptr_t)x % 16) != 0 || rows <= 0) return MVH_OK;
@@ -672,8 +679,9 @@ static int try_xty_small(hipStream_t st, const float* x, const float* dpre, floa
   int grid = (int)((rows + rpb - 1) / rpb);
   if (grid > kXtyGrid) grid = kXtyGrid;
   if (!partial || part_bytes < (size_t)grid * nout * sizeof(float)) return MVH_OK;
-  if (Cout == 3) hipLaunchKernelGGL((k_xty_small<3>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin);
-  else hipLaunchKernelGGL((k_xty_small<4>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin);
+  const int xb = x_bf16 ? 1 : 0;
+  if (Cout == 3) hipLaunchKernelGGL((k_xty_small<3>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin, xb);
+  else hipLaunchKernelGGL((k_xty_small<4>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin, xb);
   MVH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_xty_finish, dim3(1), dim3(1024), 0, st, partial, grid, nout, Cin * Cout, S, db);
   MVH_LAUNCH_CHECK();
@@ -733,8 +741,10 @@ extern "C" int mvh_cheb_conv_fwd_signs(mvh_stream_t stream, const mvh_csr_t* lap
 int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                             const float* bias, float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K,
                             int act, void* ws, size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool,
-                            float* pooled, uint8_t* bits_out, const float* weff_pre) {
+                            float* pooled, uint8_t* bits_out, const float* weff_pre, const ConvIO& io) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
+  const bool bf = io.any();
+  MVH_REQUIRE(!bf || !tx_saved, "cheb_conv_fwd: bf16 storage does not keep a T_k stack");
   MVH_REQUIRE(!bits_out || Cout % 4 == 0, "cheb_conv_fwd: sign bytes need Cout %% 4 == 0");
   auto finish = [&](bool bits_done) -> int {  // pooling / sign bytes the main kernel did not produce itself
     if (bits_out && !bits_done) {
@@ -756,23 +766,26 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
       MVH_LAUNCH_CHECK();
       weff = wbuf;
     }
-    if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act)) return rc;
+    MVH_REQUIRE(!io.out, "cheb_conv_fwd: the split path writes fp32 rows");
+    if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act, io.x)) return rc;
     bool handled = false;
     LdsConvOpts so;
-    so.prepacked = prepacked; so.in_bs = N; so.out_bs = N;
+    so.prepacked = prepacked; so.in_bs = N; so.out_bs = N; so.in_bf16 = io.x;
     if (int rc = try_cheb_lds(st, lap->sub, x, nullptr, W, bias, out, B, lap->n_active, Cin, Cout, K, act, false,
                               (float*)ws, &handled, so)) return rc;
     if (handled) {
       if (pool && pooled)
-        if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
+        if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true, io.pooled)) return rc;
       return finish(false);
     }  // otherwise fall through: the full path rewrites every row
+    if (bf) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: bf16 storage needs the LDS-resident kernel for the active block");
   }
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
     LdsConvOpts fo;
     fo.prepacked = prepacked;
+    fo.in_bf16 = io.x; fo.out_bf16 = io.out; fo.pooled_bf16 = io.pooled;
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
     fo.bits_out = bits_out;
     bool pooled_in_kernel = fo.pool_inv != nullptr;
@@ -785,10 +798,15 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     }
     if (int rc = try_cheb_lds(st, lap, x, nullptr, W, bias, out, B, N, Cin, Cout, K, act, false, wpack, &handled, fo))
       return rc;
-    if (handled && pool && !pooled_in_kernel)
-      if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
+    if (handled && pool && !pooled_in_kernel) {
+      MVH_REQUIRE(!io.out, "cheb_conv_fwd: bf16 rows are pooled inside the conv kernel only");
+      if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true, io.pooled)) return rc;
+    }
     if (handled) return finish(true);
   }
+  if (bf)
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: bf16 storage exists on the LDS-resident kernels only (N=%d %d->%d K=%d)",
+                N, Cin, Cout, K);
   float* tx = tx_saved;
   if (!tx && K > 1) {
     MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");
@@ -829,18 +847,48 @@ extern "C" int mvh_cheb_conv_bwd_signs(mvh_stream_t stream, const mvh_csr_t* lap
                             MVH_ACT_RELU, ws, ws_bytes, nullptr, nullptr, nullptr, relu_signs);
 }
 
+// bf16-storage forms of the two fused ops (BASELINE configs[1] "bf16"): x / out / dout / dx are bf16 tensors,
+// parameters and their gradients fp32, accumulation fp32.  LDS-resident kernels only (MVH_ERR_UNSUPPORTED otherwise).
+extern "C" int mvh_cheb_conv_fwd_bf16(mvh_stream_t stream, const mvh_csr_t* lap, const void* x, const float* W,
+                                      const float* bias, void* out, uint8_t* relu_signs, int32_t B, int32_t N,
+                                      int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "cheb_conv_fwd_bf16: channel counts must be multiples of 4");
+  MVH_REQUIRE(act != MVH_ACT_RELU || relu_signs, "cheb_conv_fwd_bf16: the ReLU form returns its sign bytes");
+  ConvIO io;
+  io.x = io.out = true;
+  return cheb_conv_fwd_impl((hipStream_t)stream, lap, (const float*)x, W, bias, (float*)out, nullptr, B, N, Cin, Cout, K, act,
+                            ws, ws_bytes, nullptr, nullptr, nullptr, act == MVH_ACT_RELU ? relu_signs : nullptr, nullptr, io);
+}
+
+extern "C" int mvh_cheb_conv_bwd_bf16(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const void* x,
+                                      const float* W, const uint8_t* relu_signs, const void* dout, void* dx, float* dW,
+                                      float* db, int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                                      void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "cheb_conv_bwd_bf16: channel counts must be multiples of 4");
+  MVH_REQUIRE(act != MVH_ACT_RELU || relu_signs, "cheb_conv_bwd_bf16: the ReLU form reads the forward's sign bytes");
+  ConvIO io;
+  io.x = io.dout = io.dx = true;
+  return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, (const float*)x, W, nullptr, (const float*)dout, nullptr,
+                            (float*)dx, dW, db, B, N, Cin, Cout, K, act, ws, ws_bytes, nullptr, nullptr, nullptr,
+                            act == MVH_ACT_RELU ? relu_signs : nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                            nullptr, io);
+}
+
 int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
                             const float* W, const float* out, const float* dout, const float* tx_saved, float* dx,
                             float* dW, float* db, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                             size_t ws_bytes, const float* prepacked_bwd, const mvh_csr_t* dout_pool, bool* fused_ok,
                             const uint8_t* out_bits, const float* weff_pre, DwReduceEntry* defer,
                             float* defer_part, size_t defer_bytes, bool* deferred, const mvh_csr_t* dx_pool_t,
-                            float* dx_pooled) {
+                            float* dx_pooled, const ConvIO& io) {
   if (int rc = conv_args_ok(lap, B, N, Cin, Cout, K)) return rc;
+  const bool bf = io.any();
+  MVH_REQUIRE(!bf || !tx_saved, "cheb_conv_bwd: bf16 storage does not keep a T_k stack");
+  MVH_REQUIRE(!bf || act != MVH_ACT_RELU || out_bits, "cheb_conv_bwd: bf16 storage takes the ReLU mask as sign bytes");
   if (int rc = check_csr(lap_t, "lap_t")) return rc;
   MVH_REQUIRE(lap_t->n_rows == N && lap_t->n_cols == N, "cheb_conv_bwd: lap_t shape mismatch");
   MVH_REQUIRE(x && W && dout && (dW || dx), "cheb_conv_bwd: null tensor");
-  MVH_REQUIRE(act != MVH_ACT_RELU || out, "cheb_conv_bwd: relu backward needs the forward output");
+  MVH_REQUIRE(act != MVH_ACT_RELU || out || out_bits, "cheb_conv_bwd: relu backward needs the forward output (or its sign bytes)");
   MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
@@ -875,10 +923,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd; bo.in_map = dout_pool->sel_inv; bo.in_bs = dout_pool->n_rows; bo.mask_bs = N;
     bo.mask_bits = out_bits;
+    bo.in_bf16 = io.dout; bo.out_bf16 = io.dx;
     bo.dry_run = true;
     if (!ok_dw)
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &ok_dw, 0,
-                                   dout_pool->sel_inv, dout_pool->n_rows, true, out_bits)) return rc;
+                                   dout_pool->sel_inv, dout_pool->n_rows, true, out_bits, nullptr, io.x, io.dout)) return rc;
     if (!ok_dx)
       if (int rc = try_cheb_lds(st, lap_t, dout, mask, W, nullptr, dx, B, N, Cin, Cout, K, act, true, wpack, &ok_dx, bo))
         return rc;
@@ -886,7 +935,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     bool h = false;
     if (dW) {
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, dW, db, B, N, Cin, Cout, K, partial, pbytes, &h, 0,
-                                   dout_pool->sel_inv, dout_pool->n_rows, false, out_bits, defer)) return rc;
+                                   dout_pool->sel_inv, dout_pool->n_rows, false, out_bits, defer, io.x, io.dout)) return rc;
       if (defer && h) *deferred = true;
     }
     if (dx) {
@@ -907,13 +956,14 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     const float* mask = act == MVH_ACT_RELU ? out : nullptr;
     bool h1 = false, h2 = false;
-    if (!mask)  // S_all is a plain x^T dpre reduction: stream it instead of running the LDS kernel with K = 1
-      if (int rc = try_xty_small(st, x, dout, S, db, rows, Cin, Cout, partial, pbytes, &h1)) return rc;
+    if (!mask && !io.dout)  // S_all is a plain x^T dpre reduction: stream it instead of running the LDS kernel with K = 1
+      if (int rc = try_xty_small(st, x, dout, S, db, rows, Cin, Cout, partial, pbytes, &h1, io.x)) return rc;
     if (!h1)
-      if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1)) return rc;
+      if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1, 0, nullptr, 0,
+                                   false, out_bits, nullptr, io.x, io.dout)) return rc;
     if (h1)
       if (int rc = try_cheb_dw_lds(st, lap->sub, x, dout, mask, dWsub, nullptr, B, lap->n_active, Cin, Cout, K, partial,
-                                   pbytes, &h2, N)) return rc;
+                                   pbytes, &h2, N, nullptr, 0, false, out_bits, nullptr, io.x, io.dout)) return rc;
     if (h1 && h2) {
       hipLaunchKernelGGL(k_dw_combine, dim3(cdiv(K * CC, 256)), dim3(256), 0, st, dW, dWsub, S, K, CC);
       MVH_LAUNCH_CHECK();
@@ -927,10 +977,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
       MVH_LAUNCH_CHECK();
       weff = split;
     }
-    if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act)) return rc;
+    MVH_REQUIRE(!io.dout, "cheb_conv_bwd: the split path reads an fp32 output gradient");
+    if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act, io.dx)) return rc;
     bool handled = false;
     LdsConvOpts so;
-    so.prepacked = prepacked_bwd; so.in_bs = N; so.out_bs = N;
+    so.prepacked = prepacked_bwd; so.in_bs = N; so.out_bs = N; so.out_bf16 = io.dx;
     if (int rc = try_cheb_lds(st, lap_t->sub, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B,
                               lap_t->n_active, Cin, Cout, K, act, true, wpack, &handled, so)) return rc;
     dx_done = handled;
@@ -938,10 +989,14 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
     const size_t pbytes = defer ? defer_bytes : (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
-                                 defer ? defer_part : partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits, defer))
+                                 defer ? defer_part : partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits, defer,
+                                 io.x, io.dout))
       return rc;
     if (defer && dw_done) *deferred = true;
   }
+  if (!dw_done && bf)
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dW kernels only (N=%d %d->%d K=%d)",
+                N, Cin, Cout, K);
   if (!dw_done) {
     const float* tx = tx_saved;
     if (!tx && K > 1) {
@@ -961,13 +1016,17 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd;
     bo.mask_bits = out_bits;
+    bo.in_bf16 = io.dout;
     if (dx_pool_t && dx_pooled) {  // pooled rows straight from the kernel (dx itself is not materialised)
       bo.out_pool_t = dx_pool_t;
+      bo.out_bf16 = io.dx_pooled;
       if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx_pooled, B, N, Cin,
                                 Cout, K, act, true, wpack, &handled, bo)) return rc;
       if (handled) return MVH_OK;
       bo.out_pool_t = nullptr;
+      if (bf) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage pools dx inside the dX kernel only");
     }
+    bo.out_bf16 = io.dx;
     if (int rc = try_cheb_lds(st, lap_t, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B, N, Cin,
                               Cout, K, act, true, wpack, &handled, bo)) return rc;
     if (handled) {
@@ -975,6 +1034,9 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
       return MVH_OK;
     }
   }
+  if (bf)
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dX kernels only (N=%d %d->%d K=%d)",
+                N, Cin, Cout, K);
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
   float* g0 = (K == 1) ? dx : G;
   if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act)) return rc;

@@ -19,6 +19,7 @@
 // Per (mesh, slab, wave, order) a 16 x 4 partial tile goes to a workspace; a second launch sums
 // the partials in fixed order (bitwise reproducible, no atomics) and scatters them into dW / db.
 #include "common.hpp"
+#include "bf16.hpp"
 
 #include <type_traits>
 
@@ -33,6 +34,7 @@ struct DwDims {
                                            // from a compact buffer of map_bs rows per mesh (masks stay full-size)
   int mask_bits;                           // the mask pointer holds ReLU sign bytes (one per vertex and 4 channels)
   int ovf;                                 // MVH_CSR_ELL_OVERFLOW: rows longer than 8 continue in the CSR columns
+  int p_bf16, q_bf16;                      // the P / Q tensor is stored as bf16 (bf16.hpp); masks are sign bytes then
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -113,6 +115,11 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
   for (int h = 0; h < QH; ++h) qsum[h] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Qb = p_Q + (long long)mesh * (a.map_side == 2 ? a.map_bs : a.bs) * CQT;
+  const uint16_t* Qh = reinterpret_cast<const uint16_t*>(p_Q) + (long long)mesh * (a.map_side == 2 ? a.map_bs : a.bs) * CQT;
+  const bool qbf = a.q_bf16 != 0, pbf = a.p_bf16 != 0;
+  // element offsets of this mesh in the Q / P tensors (load*_any index from the tensor's base: the element size differs)
+  const long long qoff = (long long)mesh * (a.map_side == 2 ? a.map_bs : a.bs) * CQT;
+  const long long poff = (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
   const float* Qm = (p_Qmask && !a.mask_bits) ? p_Qmask + (long long)mesh * a.bs * CQT : nullptr;
   const uint8_t* Qbits = (p_Qmask && a.mask_bits)
                              ? reinterpret_cast<const uint8_t*>(p_Qmask) + (long long)mesh * a.bs * (CQT / 4) : nullptr;
@@ -120,7 +127,8 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   // body is branch-free, so the scheduler can keep the loads of many steps in flight; the general loop
   // below has wave-uniform branches per step, which serialise its 40 global loads at the 5k level.
   const bool fast_q = !SPLIT && Qbits != nullptr && a.map_side != 2 && (CQ % 16 == 0);
-  if (fast_q) {
+  auto load_q_fast = [&](auto bf_tag) {
+    constexpr bool kBF = decltype(bf_tag)::value;
 #pragma unroll
     for (int s = 0; s < STEPS_CT; ++s) {
       const int v = 16 * (s * NW + wave) + (lane >> 2);
@@ -132,7 +140,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
 #pragma unroll
       for (int h = 0; h < QH; ++h) {
         const int c0 = 16 * h + 4 * (lane & 3);
-        float4 t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
+        float4 t;
+        if constexpr (kBF) t = bf16_unpack4(*reinterpret_cast<const uint2*>(Qh + (long long)vl * CQ + c0));
+        else t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
         const uint32_t m = Qbits[vl * (CQ / 4) + (c0 >> 2)];
         t.x = (m & 1u) ? t.x : 0.f;
         t.y = (m & 2u) ? t.y : 0.f;
@@ -145,6 +155,10 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         qreg[SPLIT ? 0 : s][h] = make_float4(t.x * inv_s, t.y * inv_s, t.z * inv_s, t.w * inv_s);
       }
     }
+  };
+  if (fast_q) {
+    if (a.q_bf16) load_q_fast(std::true_type{});
+    else load_q_fast(std::false_type{});
   } else
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
@@ -162,7 +176,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
     if constexpr (SPLIT) {
       const long long off = (long long)ql * CQT + q0 + (lane & 3);
-      float t = qhave ? Qb[off] : 0.f;
+      float t = qhave ? load1_any(p_Q, qoff + off, qbf) : 0.f;
       if (Qm && !(Qm[(long long)vl * CQT + q0 + (lane & 3)] > 0.f)) t = 0.f;
       if (Qbits && !((Qbits[vl * (CQT / 4) + (q0 >> 2)] >> (lane & 3)) & 1)) t = 0.f;
       if (valid) qsum[0].x += t;
@@ -174,7 +188,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       const int c0 = 16 * h + 4 * (lane & 3);
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c0 < CQ) {
-        t = *reinterpret_cast<const float4*>(Qb + (long long)ql * CQ + c0);
+        t = load4_any(p_Q, qoff + (long long)ql * CQ + c0, qbf);
         if (!qhave) t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Qm) {
           const float4 m = *reinterpret_cast<const float4*>(Qm + (long long)vl * CQ + c0);
@@ -226,14 +240,16 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   uint4 ids[kDB ? VPT : 1];
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* Pb = p_P + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
+  const uint16_t* Ph = reinterpret_cast<const uint16_t*>(p_P) + (long long)mesh * (a.map_side == 1 ? a.map_bs : a.bs) * a.CP;
   const float* Pm = (p_Pmask && !a.mask_bits) ? p_Pmask + (long long)mesh * a.bs * a.CP : nullptr;
   const uint8_t* Pbits = (p_Pmask && a.mask_bits)
                              ? reinterpret_cast<const uint8_t*>(p_Pmask) + (long long)mesh * a.bs * (a.CP >> 2) : nullptr;
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
   // (as in cheb_lds.hip: the wave-uniform mode branches would fence each vertex's loads, so the loop is
   //  instantiated per mode -- 0 plain full slab, 1 fp32 mask, 2 sign bytes, 3 general (row map, partial slab))
-  auto load_p = [&](auto mode_tag) {
+  auto load_p = [&](auto mode_tag, auto bf_tag) {
     constexpr int kMode = decltype(mode_tag)::value;
+    constexpr bool kBF = decltype(bf_tag)::value;
   #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       const int v = tid + vi * THREADS;
@@ -272,7 +288,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         }
       }
       if (kMode != 3 || slab_full) {
-        float4 tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
+        float4 tv;
+        if constexpr (kBF) tv = bf16_unpack4(*reinterpret_cast<const uint2*>(Ph + (long long)pl * a.CP + s0));
+        else tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
         if (!phave) tv = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((kMode == 1 || kMode == 3) && Pm) {
           const float4 m = *reinterpret_cast<const float4*>(Pm + (long long)vl * a.CP + s0);
@@ -293,7 +311,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (s0 + j < a.CP) {
-            float x = phave ? Pb[(long long)pl * a.CP + s0 + j] : 0.f;
+            float x = phave ? load1_any(p_P, poff + (long long)pl * a.CP + s0 + j, kBF) : 0.f;
             if (Pm && !(Pm[(long long)vl * a.CP + s0 + j] > 0.f)) x = 0.f;
             t[j] = x;
           }
@@ -307,10 +325,21 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  if (a.map_side == 1 || !slab_full) load_p(std::integral_constant<int, 3>{});
-  else if (Pbits) load_p(std::integral_constant<int, 2>{});
-  else if (Pm) load_p(std::integral_constant<int, 1>{});
-  else load_p(std::integral_constant<int, 0>{});
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    const int pm = (a.map_side == 1 || !slab_full) ? 3 : (Pbits ? 2 : (Pm ? 1 : 0));
+    if (pbf) {  // (bf16 rows never come with an fp32 mask: mode 1 does not exist for them)
+      if (pm == 3) load_p(std::integral_constant<int, 3>{}, T{});
+      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, T{});
+      else load_p(std::integral_constant<int, 0>{}, T{});
+    } else {
+      if (pm == 3) load_p(std::integral_constant<int, 3>{}, F{});
+      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, F{});
+      else if (pm == 1) load_p(std::integral_constant<int, 1>{}, F{});
+      else load_p(std::integral_constant<int, 0>{}, F{});
+    }
+  }
   if (a.db_mode == 2 && q0 == 0) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
     float* pk = part + (long long)a.K * CQT * 4;
     float v4[4] = {psum.x, psum.y, psum.z, psum.w};
@@ -573,7 +602,7 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
-                    const uint8_t* out_bits, DwReduceEntry* defer) {
+                    const uint8_t* out_bits, DwReduceEntry* defer, bool x_bf16, bool dout_bf16) {
   *handled = false;
   if (dbg().force_generic) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
@@ -597,6 +626,9 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (!part || part_bytes < need_bytes) return MVH_OK;
 
   if (out_bits && Cout % 4 != 0) out_bits = nullptr;  // sign bytes cover whole 4-channel groups only
+  // bf16 tensors are read in 4-channel words; a ReLU mask then comes as sign bytes (never the fp32 output)
+  if ((x_bf16 && Cin % 4 != 0) || (dout_bf16 && Cout % 4 != 0)) return MVH_OK;
+  if ((x_bf16 || dout_bf16) && out_mask && !out_bits) return MVH_OK;
   if (dry_run) {
     *handled = true;
     return MVH_OK;
@@ -610,6 +642,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   d.bs = bstride > 0 ? bstride : N;
   d.map_side = dout_map ? (p_is_x ? 2 : 1) : 0;  // dout is Q when x runs the recurrence, else P
   d.map_bs = dout_rows;
+  d.p_bf16 = (p_is_x ? x_bf16 : dout_bf16) ? 1 : 0;
+  d.q_bf16 = (p_is_x ? dout_bf16 : x_bf16) ? 1 : 0;
   const float* P = p_is_x ? x : dout;
   const float* Pm = p_is_x ? nullptr : out_mask;
   const float* Q = p_is_x ? dout : x;

@@ -22,6 +22,7 @@
 // Replaces 5 propagate launches + 1 contraction of the stack pipeline with one launch whose
 // HBM traffic is the module boundary: read In once (per slab, L2-shared), write out once.
 #include "common.hpp"
+#include "bf16.hpp"
 
 #include <type_traits>
 
@@ -49,6 +50,7 @@ struct LdsConvArgs {
   const int* pt_col;        // the kernel and ONLY the pooled rows [B][pt_rows][CO] are stored to `out`
   const float* pt_val;
   int pt_rows;
+  int in_bf16, out_bf16, pooled_bf16;  // storage type of in / out / pooled: bf16 instead of fp32 (bf16.hpp)
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -61,6 +63,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
   int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows, ovf;
+  int in_bf16, out_bf16, pooled_bf16;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -116,6 +119,8 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   uint32_t ovf0[kOvf ? VPT : 1], ovf1[kOvf ? VPT : 1];
   bool ovf_any[kOvf ? VPT : 1];
   const float* inb = p_in + (long long)mesh * a.in_bs * CQ;
+  // bf16 storage: the same rows as 2-byte elements (CQ % 4 == 0; the host checks)
+  const uint16_t* inh = reinterpret_cast<const uint16_t*>(p_in) + (long long)mesh * a.in_bs * CQ;
   const bool use_bits = BWD && p_mask && a.mask_bits && (CQ % 4 == 0);
   const float* mkb = (BWD && p_mask && !use_bits) ? p_mask + (long long)mesh * a.mask_bs * CQ : nullptr;
   // ReLU sign bytes written by the forward kernel: CQ/4 bytes per vertex, bit j of byte c/4 = out[v][c+j] > 0
@@ -123,9 +128,10 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   // The row map and the mask mode are wave-uniform; as run-time branches they would fence every vertex's
   // loads into its own basic block (one memory round trip per vertex).  The loop is therefore a generic
   // lambda instantiated per (map, mask mode) and dispatched once, so each copy is straight-line code.
-  auto load_rows = [&](auto map_tag, auto mask_tag) {
+  auto load_rows = [&](auto map_tag, auto mask_tag, auto bf_tag) {
     constexpr bool kMap = decltype(map_tag)::value;
     constexpr int kMask = decltype(mask_tag)::value;  // 0 none, 1 fp32 mask, 2 sign bytes
+    constexpr bool kBF = decltype(bf_tag)::value;     // input rows stored as bf16
   #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       const int v = tid + vi * THREADS;
@@ -179,9 +185,25 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
             }
           }
         }
+        float4 tv[CQ / 4];
+        if constexpr (kBF && CQ % 8 == 0) {          // 16-byte loads: 8 channels each
+  #pragma unroll
+          for (int c = 0; c < CQ; c += 8) {
+            const uint4 w = *reinterpret_cast<const uint4*>(inh + (long long)rl * CQ + c);
+            tv[c / 4] = bf16_unpack4(make_uint2(w.x, w.y));
+            tv[c / 4 + 1] = bf16_unpack4(make_uint2(w.z, w.w));
+          }
+        } else if constexpr (kBF) {
+  #pragma unroll
+          for (int c = 0; c < CQ; c += 4)
+            tv[c / 4] = bf16_unpack4(*reinterpret_cast<const uint2*>(inh + (long long)rl * CQ + c));
+        } else {
+  #pragma unroll
+          for (int c = 0; c < CQ; c += 4) tv[c / 4] = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
+        }
   #pragma unroll
         for (int c = 0; c < CQ; c += 4) {
-          float4 t = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
+          float4 t = tv[c / 4];
           if constexpr (kMask == 2) {
             const uint32_t m = mw[c / 16] >> (2 * (c % 16));
             t.x = (m & 1u) ? t.x : 0.f;
@@ -220,14 +242,27 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
     const int mm = use_bits ? 2 : (mkb ? 1 : 0);
-    if (p_in_map) {
-      if (mm == 2) load_rows(T{}, M2{});
-      else if (mm == 1) load_rows(T{}, M1{});
-      else load_rows(T{}, M0{});
-    } else {
-      if (mm == 2) load_rows(F{}, M2{});
-      else if (mm == 1) load_rows(F{}, M1{});
-      else load_rows(F{}, M0{});
+    if constexpr (CQ % 4 == 0) {
+      if (a.in_bf16) {  // (bf16 rows come with sign bytes or no mask: the host refuses an fp32 mask)
+        if (p_in_map) {
+          if (mm == 2) load_rows(T{}, M2{}, T{});
+          else load_rows(T{}, M0{}, T{});
+        } else {
+          if (mm == 2) load_rows(F{}, M2{}, T{});
+          else load_rows(F{}, M0{}, T{});
+        }
+      }
+    }
+    if (CQ % 4 != 0 || !a.in_bf16) {
+      if (p_in_map) {
+        if (mm == 2) load_rows(T{}, M2{}, F{});
+        else if (mm == 1) load_rows(T{}, M1{}, F{});
+        else load_rows(T{}, M0{}, F{});
+      } else {
+        if (mm == 2) load_rows(F{}, M2{}, F{});
+        else if (mm == 1) load_rows(F{}, M1{}, F{});
+        else load_rows(F{}, M0{}, F{});
+      }
     }
   }
 
@@ -443,9 +478,10 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     float* dst = outb + (long long)v * a.CO + s0;
     const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
-    if (vec_store) {
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-      if (pr >= 0) *reinterpret_cast<float4*>(pdst) = make_float4(o[0], o[1], o[2], o[3]);
+    if (vec_store) {  // (bf16 storage: the host guarantees CO % 4 == 0, i.e. this branch)
+      store4_any(p_out, ((long long)mesh * a.out_bs + v) * a.CO + s0, a.out_bf16 != 0, o[0], o[1], o[2], o[3]);
+      if (pr >= 0)
+        store4_any(p_pooled, ((long long)mesh * a.pooled_bs + pr) * a.CO + s0, a.pooled_bf16 != 0, o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -483,8 +519,8 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           acc.w = __fadd_rn(acc.w, __fmul_rn(w[t], n[t].w));
         }
       }
-      float* pb = BWD ? outb : p_pooled + (long long)mesh * a.pooled_bs * a.CO;
-      *reinterpret_cast<float4*>(pb + (long long)c * a.CO + s0) = acc;
+      if (BWD) store4_any(p_out, ((long long)mesh * a.out_bs + c) * a.CO + s0, a.out_bf16 != 0, acc.x, acc.y, acc.z, acc.w);
+      else store4_any(p_pooled, ((long long)mesh * a.pooled_bs + c) * a.CO + s0, a.pooled_bf16 != 0, acc.x, acc.y, acc.z, acc.w);
     }
   }
 }
@@ -555,7 +591,7 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
-                a.mask_bits, a.pt_rows, a.ovf};
+                a.mask_bits, a.pt_rows, a.ovf, a.in_bf16, a.out_bf16, a.pooled_bf16};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
                      a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, a.col, d);
   MVH_LAUNCH_CHECK();
@@ -615,6 +651,10 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
 
   LdsConvArgs a;
   a.mask_bits = 0; a.bits_out = nullptr;
+  a.in_bf16 = o.in_bf16 ? 1 : 0; a.out_bf16 = o.out_bf16 ? 1 : 0; a.pooled_bf16 = o.pooled_bf16 ? 1 : 0;
+  // bf16 rows are read / written in 4-channel words, and a ReLU mask comes as sign bytes (never the fp32 output)
+  if (o.in_bf16 && (CQ % 4 != 0 || (mask && !o.mask_bits))) return MVH_OK;
+  if ((o.out_bf16 || o.pooled_bf16) && CO % 4 != 0) return MVH_OK;
   if (o.mask_bits) {  // sign bytes take the place of the float mask
     if (!bwd || CQ % 4 != 0) return MVH_OK;
     mask = reinterpret_cast<const float*>(o.mask_bits);

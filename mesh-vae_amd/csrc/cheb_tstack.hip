@@ -16,6 +16,7 @@
 // Replaces the LDS-resident dW kernel for this layer (4 workgroups per mesh each re-running the
 // recurrence, 64 + 5 us at the end of the backward critical path) by a 5 us reduction.
 #include "common.hpp"
+#include "bf16.hpp"
 
 namespace mvh {
 
@@ -116,6 +117,7 @@ constexpr int kSdwGrid = 256;
 
 struct SdwDims {
   int rows, n_sel, N, K, Cin, Cout;
+  int dout_bf16;  // dout (the gradient of the pooled output) is stored as bf16
 };
 
 constexpr int kSdwRows = 64;  // rows per LDS tile
@@ -147,7 +149,7 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
     const int b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
     if (tx < a.K) pa = *reinterpret_cast<const float4*>(stack + (((long long)b * (a.N + 1) + v) * a.K + tx) * 4);
     if (tx < CQ4) {
-      float4 d = *reinterpret_cast<const float4*>(dout + (long long)r * a.Cout + tx * 4);
+      float4 d = load4_any(dout, (long long)r * a.Cout + tx * 4, a.dout_bf16 != 0);
       if (bits) {
         const uint32_t m = bits[((long long)b * a.N + v) * CQ4 + tx];
         d.x = (m & 1u) ? d.x : 0.f;
@@ -239,8 +241,8 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
 // dW [K][Cin][Cout], db [Cout] from the stack and the gradient of the POOLED output dout [B][n_sel][Cout]
 int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,
                     const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K,
-                    DwReduceEntry* defer) {
-  SdwDims d{B * pool->n_rows, pool->n_rows, N, K, Cin, Cout};
+                    DwReduceEntry* defer, bool dout_bf16) {
+  SdwDims d{B * pool->n_rows, pool->n_rows, N, K, Cin, Cout, dout_bf16 ? 1 : 0};
   int grid = (d.rows + kSdwRows - 1) / kSdwRows;
   if (grid > kSdwGrid) grid = kSdwGrid;
   hipLaunchKernelGGL(k_stack_dw, dim3(grid), dim3(512), 0, st, stack, dout, bits, out_mask, pool->col, partial, d);

@@ -57,7 +57,8 @@ DebugCfg& dbg();
 
 // ---- internal launchers shared between translation units (all async on `st`)
 int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, const float* add,
-                const float* z, float alpha, float beta, int B, int C, bool exact);
+                const float* z, float alpha, float beta, int B, int C, bool exact,
+                bool y_bf16 = false /* y is stored as bf16 (C % 4 == 0 only) */);
 // C[M,N] = A (M x K, strides sam,sak) * Bm (K x N, strides sbk,sbn) (+bias[n]) -> act -> dropout
 int launch_gemm(hipStream_t st, const float* A, long long sam, long long sak, const float* Bm,
                 long long sbk, long long sbn, float* C, int M, int N, int K, const float* bias,
@@ -91,6 +92,9 @@ struct LdsConvOpts {
   // pool the result rows with this CSR (n_cols = N) inside the kernel.  Backward: `out` is then the pooled
   // buffer [B][n_rows][CO] and the un-pooled rows are never stored; forward: `out` as usual, pooled rows to `pooled`
   const mvh_csr_t* out_pool_t = nullptr;
+  // bf16 STORAGE of the activation tensors (bf16.hpp): `in`, `out` (backward with out_pool_t: the pooled buffer) and
+  // `pooled` are then 2-byte tensors behind the float pointers; arithmetic and the LDS state stay fp32
+  bool in_bf16 = false, out_bf16 = false, pooled_bf16 = false;
 };
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
@@ -106,13 +110,22 @@ struct PackTable {
 };
 int pack_entry_floats(int Cin, int Cout, int K, bool bwd);
 int launch_pack_all(hipStream_t st, const PackTable& t);
+// Storage type of the activation tensors of one conv call (bf16.hpp): true = 2-byte bf16 elements behind the float
+// pointer.  bf16 tensors exist only on the LDS-resident / split paths; a layer that would need the general stack
+// pipeline fails with MVH_ERR_UNSUPPORTED instead of falling back.
+struct ConvIO {
+  bool x = false, out = false, pooled = false;          // forward: input, output, fused-pooling output
+  bool dout = false, dx = false, dx_pooled = false;     // backward: output gradient, input gradient, its pooled form
+  bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
+};
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
 int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias,
                        float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
                        size_t ws_bytes, const float* prepacked, const mvh_csr_t* pool = nullptr,
                        float* pooled = nullptr /* fused one-hot pooling of the output (falls back to a launch) */,
                        uint8_t* bits_out = nullptr /* ReLU sign bytes [B][N][Cout/4] of the output (Cout % 4 == 0) */,
-                       const float* weff_pre = nullptr /* W_eff already built by launch_pack_all (split path) */);
+                       const float* weff_pre = nullptr /* W_eff already built by launch_pack_all (split path) */,
+                       const ConvIO& io = ConvIO());
 int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x, const float* W,
                        const float* out, const float* dout, const float* tx_saved, float* dx, float* dW, float* db,
                        int B, int N, int Cin, int Cout, int K, int act, void* ws, size_t ws_bytes,
@@ -125,7 +138,8 @@ int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* la
                        float* defer_part = nullptr    /* there and *defer describes the pending reduction         */,
                        size_t defer_bytes = 0, bool* deferred = nullptr,
                        const mvh_csr_t* dx_pool_t = nullptr /* store dx_pooled = dx_pool_t * dx instead of dx (the      */,
-                       float* dx_pooled = nullptr           /* decoder's upsampling backward); falls back to dx + spmm */);
+                       float* dx_pooled = nullptr           /* decoder's upsampling backward); falls back to dx + spmm */,
+                       const ConvIO& io = ConvIO());
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
@@ -135,7 +149,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     const int32_t* dout_map = nullptr, int dout_rows = 0 /* dout row v = dout[map[v]] (zero if < 0),
                                                                             compact buffer of dout_rows per mesh */,
                     bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */,
-                    DwReduceEntry* defer = nullptr /* skip the reduce launch and describe it here instead */);
+                    DwReduceEntry* defer = nullptr /* skip the reduce launch and describe it here instead */,
+                    bool x_bf16 = false, bool dout_bf16 = false /* storage type of x / dout (bf16.hpp) */);
 
 // first-layer weight gradient through a saved Chebyshev stack (cheb_tstack.hip)
 size_t tstack_stack_floats(int B, int N, int K);
@@ -145,7 +160,8 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
                   int N, int Cin, int K);
 int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,
                     const float* out_mask, float* dW, float* db, float* partial, int B, int N, int Cin, int Cout, int K,
-                    DwReduceEntry* defer = nullptr /* leave the final sum to launch_dw_reduce_all */);
+                    DwReduceEntry* defer = nullptr /* leave the final sum to launch_dw_reduce_all */,
+                    bool dout_bf16 = false);
 // mvh_vae_loss_fwd with optional gradient seeds for d_loss = 1 (d_recon [B*NV], d_mu/d_logvar [B*Z], d_yhat [B*C])
 int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
                   const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss, void* rec,

@@ -5,6 +5,7 @@
 // 16-byte loads; the 4..8 lanes of a row read the same col/val words (wave broadcast).
 // HBM-bound; the gathers are served by L2 (one mesh level is <= 320 KB).
 #include "common.hpp"
+#include "bf16.hpp"
 
 namespace mvh {
 
@@ -81,7 +82,7 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
        int n_rows, int n_cols, const float* __restrict__ x, float* y,
        const float* add, const float* z,  // y may alias add (in-place Clenshaw update)
        float alpha, float beta, int C,
-       int wg_per_mesh, int xcd_remap) {
+       int wg_per_mesh, int xcd_remap, int y_bf16) {
   // One mesh = wg_per_mesh consecutive tiles.  Workgroup ids are dealt round-robin to the 8 XCDs, each with
   // its own 4 MB L2; with the linear order every XCD touches every mesh and the ~7 gathers per row (a 20k-vertex
   // level is 1.3 MB per mesh at 16 channels) miss L2 and go to MALL/HBM.  Remapped, XCD x walks the meshes
@@ -180,16 +181,18 @@ k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const float*
     acc[i] = res;
   }
   if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(y + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    store4_any(y, o, y_bf16 != 0, acc[0], acc[1], acc[2], acc[3]);
   } else {
     y[o] = acc[0];
   }
 }
 
 int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, const float* add,
-                const float* z, float alpha, float beta, int B, int C, bool exact) {
+                const float* z, float alpha, float beta, int B, int C, bool exact, bool y_bf16) {
   if (B == 0 || op->n_rows == 0 || C == 0) return MVH_OK;
   const bool v4 = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)z) % 16 == 0);
+  if (y_bf16 && (!v4 || add || z)) return fail(MVH_ERR_UNSUPPORTED, "spmm: bf16 output needs 4-channel groups and no add/z terms");
+  const int yb = y_bf16 ? 1 : 0;
   if (C == 3 && !exact && op->n_rows >= 4096) {  // big level, three channels: one lane per row
     const int wpm = cdiv(op->n_rows, 256);
     MVH_REQUIRE((long long)B * wpm < (1ll << 31), "spmm: grid too large");
@@ -209,7 +212,7 @@ int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, c
   const int xcd_remap = (B % 8 == 0 && wg_per_mesh >= 16 && !dbg().no_xcd_remap) ? 1 : 0;
 #define MVH_SPMM(V, E)                                                                             \
   hipLaunchKernelGGL((k_spmm<V, E>), dim3(grid), dim3(256), 0, st, op->rowptr, op->col, op->val,   \
-                     op->n_rows, op->n_cols, x, y, add, z, alpha, beta, C, wg_per_mesh, xcd_remap)
+                     op->n_rows, op->n_cols, x, y, add, z, alpha, beta, C, wg_per_mesh, xcd_remap, yb)
   if (v4) {
     if (exact) MVH_SPMM(4, true); else MVH_SPMM(4, false);
   } else {

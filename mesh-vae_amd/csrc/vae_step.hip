@@ -209,6 +209,9 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   ParamIdx ix{n};
   void* sm = (char*)ws + p.scratch_main;
   const float pd = drop_u ? d->dropout_p : 0.f;
+  // storage == MVH_STORAGE_BF16: every conv-level activation between two layers is a bf16 tensor (the buffers of
+  // the plan keep their fp32 sizes); the network input, the reconstruction and the dense head stay fp32
+  const bool bf = d->storage == MVH_STORAGE_BF16;
   // dropout uniforms: [B, H | H | H | flat] per row (encoder h, classifier, dec_lin, dec_lin_2)
   const int urow = 3 * p.H + p.flat;
   (void)urow;
@@ -241,9 +244,12 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   const float* cur = x;
   for (int i = 0; i < n && (phases & kPhEnc); ++i) {
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
-    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]), TX(p.txEnc[i]), B,
+    ConvIO io;
+    io.x = bf && i > 0; io.out = bf; io.pooled = bf && i + 1 < n;   // (the last pooled level feeds the fp32 dense head)
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]),
+                           bf ? nullptr : TX(p.txEnc[i]), B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
-                           &d->down[i], F(p.encP[i]), BITS(p.encBits[i])));
+                           &d->down[i], F(p.encP[i]), BITS(p.encBits[i]), nullptr, io));
     cur = F(p.encP[i]);
   }
   if (phases & kPhEnc)
@@ -260,19 +266,27 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   TRY(mvh_linear_fwd(stream, F(p.d1), P[ix.dl2W()], P[ix.dl2B()], F(p.d2), B, p.H, p.flat, MVH_ACT_RELU, u_d2, pd));
   // the first upsampling takes the dense head's output; the later ones are produced by the previous
   // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
-  TRY(mvh_pool_fwd(stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), B, p.f[n + 1]));
+  TRY(check_csr(&d->up[n - 1], "up"));
+  TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
+    ConvIO io;
+    io.x = io.out = io.pooled = bf;
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
-                           TX(p.txDec[i]), B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_f[i]),
-                           more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr, BITS(p.decBits[i])));
+                           bf ? nullptr : TX(p.txDec[i]), B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes,
+                           F(p.pk_dec_f[i]), more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr,
+                           BITS(p.decBits[i]), nullptr, io));
     cur = F(p.decC[i]);
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
-  TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
-                         p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n]), nullptr, nullptr, nullptr,
-                         F(p.weff_final)));
+  {
+    ConvIO io;
+    io.x = bf;   // (the reconstruction itself is an fp32 tensor)
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
+                           p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n]), nullptr, nullptr, nullptr,
+                           F(p.weff_final), io));
+  }
   if (!(phases & kPhLoss)) return MVH_OK;
   // ---- loss (cheb_VAE.py:321-346)
   // (the gradient seeds of a d_loss = 1 backward come out of the same two launches)
@@ -326,6 +340,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   void* sm = (char*)ws + p.scratch_main;
   void* ss = (char*)ws + p.scratch_side;
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
+  const bool bf = d->storage == MVH_STORAGE_BF16;   // bf16 activations and activation gradients (see the forward)
   const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
   const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
@@ -350,6 +365,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     const mvh_csr_t *dout_pool, *unpool_t;  // dout is the gradient of the POOLED output (fused un-pooling);
     float* unpooled;                        // fallback: un-pool with unpool_t into this buffer first
     const float* tx;                        // T_k stack kept by the forward (big levels), else null
+    ConvIO io;
   };
   PendingDw pending[4];
   int n_pending = 0;
@@ -371,7 +387,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
         TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, w.tx, nullptr, w.dW, w.db, B, w.N,
                                w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, w.dout_pool, &fused, w.bits,
                                nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
-                               &deferred));
+                               &deferred, nullptr, nullptr, w.io));
+        MVH_REQUIRE(fused || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the weight-gradient kernel");
         if (!fused) {  // not eligible: explicit un-pooling on this lane, then the plain call below
           TRY(mvh_pool_bwd((mvh_stream_t)sstream, w.unpool_t, w.dout, w.unpooled, B, w.cout));
           dout = w.unpooled;
@@ -380,7 +397,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (!fused)
         TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, w.tx, nullptr, w.dW, w.db, B, w.N,
                                w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
-                               can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred));
+                               can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred,
+                               nullptr, nullptr, w.io));
       if (deferred) ++red.n;
     }
     n_pending = 0;
@@ -388,21 +406,21 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   auto conv_dw_side = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dW, float* db, int N, int cin, int cout,
-                          int K, int act, const uint8_t* bits, size_t part_off = kNoBits, size_t part_bytes = 0,
-                          const mvh_csr_t* dout_pool = nullptr, const mvh_csr_t* unpool_t = nullptr,
+                          int K, int act, const uint8_t* bits, const ConvIO& io, size_t part_off = kNoBits,
+                          size_t part_bytes = 0, const mvh_csr_t* dout_pool = nullptr, const mvh_csr_t* unpool_t = nullptr,
                           float* unpooled = nullptr, const float* tx = nullptr) -> int {
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
-                                     dout_pool, unpool_t, unpooled, tx};
+                                     dout_pool, unpool_t, unpooled, tx, io};
     if (n_pending >= fork_batch) return flush_dw(false);
     return MVH_OK;
   };
   auto conv_dx_main = [&](const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* xin, const float* W,
                           const float* out, const float* dout, float* dx, int N, int cin, int cout, int K,
-                          int act, size_t pk, const uint8_t* bits, const float* weff = nullptr,
+                          int act, size_t pk, const uint8_t* bits, const ConvIO& io, const float* weff = nullptr,
                           const mvh_csr_t* pool_t = nullptr, float* pooled = nullptr) -> int {
     return cheb_conv_bwd_impl(main, lap, lap_t, xin, W, out, dout, nullptr, dx, nullptr, nullptr, B, N, cin, cout, K,
                               act, sm, p.scratch_bytes, F(pk), nullptr, nullptr, bits, weff, nullptr, nullptr, 0,
-                              nullptr, pool_t, pooled);
+                              nullptr, pool_t, pooled, io);
   };
 
   // ---- loss: mvh_vae_forward already left the d_loss = 1 seeds in the workspace
@@ -412,17 +430,22 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // ---- final conv
   {
     const float* xin = F(p.decC[n - 1]);
+    ConvIO io;
+    io.x = bf; io.dx = bf;   // (g_recon is fp32)
     TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
-                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr));
+                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr, io));
     TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
-                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr, F(p.weff_final)));
+                     p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr, io, F(p.weff_final)));
   }
   // ---- decoder stages, last to first
   for (int i = n - 1; i >= 0; --i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
+    ConvIO io;
+    io.x = io.dout = io.dx = bf;
+    io.dx_pooled = bf && i > 0;   // (stage 0 hands its pooled gradient to the fp32 dense head)
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]),
-                     p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, TX(p.txDec[i])));
+                     G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
+                     p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));
     if (i == n - 1 && use_tstack) {
       // T_k x of encoder layer 0 at its pooled rows: 64 workgroups on the side lane behind the (chip-filling)
       // dW above, i.e. while the main chain runs its small-level kernels; consumed at the very end
@@ -436,7 +459,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]),
+                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]), io,
                      nullptr, &d->up_t[lvl], dst));
   }
   // ---- dense decoder head, latent heads, dense encoder head: the dX chain stays on the main stream,
@@ -476,24 +499,29 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // zero-filled [B, N_i, C] gradient tensor); if a layer is not eligible it is un-pooled explicitly.
   for (int i = n - 1; i >= 0; --i) {
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
+    ConvIO io;
+    io.x = bf && i > 0; io.dout = bf && i + 1 < n; io.dx = bf;   // (the last level's gradient comes from the fp32 dense head)
     if (i > 0) {
       // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible);
       // with the stack path layer 0 costs the main stream only ~10 us, so layer 1's dW runs there after it
       // instead of at the end of the side lane's backlog (debug switch tail_main = 0: side lane as usual)
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
-                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]),
-                       p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i]), TX(p.txEnc[i])));
+                       G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]), io,
+                       p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i]),
+                       bf ? nullptr : TX(p.txEnc[i])));
       bool ok_dx = false;
       TRY(cheb_conv_bwd_impl(main, &d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), nullptr,
                              F(p.g_encP[i - 1]), nullptr, nullptr, B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU,
-                             sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx, BITS(p.encBits[i])));
+                             sm, p.scratch_bytes, F(p.pk_enc_b[i]), &d->down[i], &ok_dx, BITS(p.encBits[i]), nullptr, nullptr,
+                             nullptr, 0, nullptr, nullptr, nullptr, io));
+      MVH_REQUIRE(ok_dx || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the dX kernel");
       if (!ok_dx) {  // (its own un-pooled copy: the side lane may be writing g_encA for the dW fallback)
         // (decoder buffer of the same level, free by now, when it is wide enough)
         float* tmp = (p.f[i + 2] >= p.f[i + 1]) ? F(p.g_decU[n - 1 - i]) : F(p.g_encA[i]);
         TRY(mvh_pool_bwd(stream, &d->down_t[i], F(p.g_encP[i]), tmp, B, p.f[i + 1]));
         TRY(conv_dx_main(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), tmp, F(p.g_encP[i - 1]), p.Nn[i],
-                         p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i])));
+                         p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, p.pk_enc_b[i], BITS(p.encBits[i]), io));
       }
       continue;
     }
@@ -505,15 +533,18 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (ev_tstack) MVH_HIP(hipStreamWaitEvent(main, ev_tstack, 0));
       TRY(launch_stack_dw(main, &d->down[0], F(p.tstack), F(p.g_encP[0]), BITS(p.encBits[0]), F(p.encA[0]),
                           G[ix.encW(0)], G[ix.encB(0)], F(p.tstack) + tstack_stack_floats(B, p.Nn[0], d->K[0]), B, p.Nn[0],
-                          p.f[0], p.f[1], d->K[0], &red.e[red.n]));
+                          p.f[0], p.f[1], d->K[0], &red.e[red.n], io.dout));
       ++red.n;
       if (tail_on_main && n > 1) {
         bool fused = false, dfr = false;
         const float* xin1 = F(p.encP[0]);
+        ConvIO io1;
+        io1.x = bf; io1.dout = bf && n > 2;
         TRY(cheb_conv_bwd_impl(main, &d->lap[1], &d->lap_t[1], xin1, P[ix.encW(1)], F(p.encA[1]), F(p.g_encP[1]), nullptr,
                                nullptr, G[ix.encW(1)], G[ix.encB(1)], B, p.Nn[1], p.f[1], p.f[2], d->K[1], MVH_ACT_RELU, sm,
                                p.scratch_bytes, nullptr, &d->down[1], &fused, BITS(p.encBits[1]), nullptr, &red.e[red.n],
-                               F(p.dwPartEnc[1]), p.dwPartBytesEnc[1], &dfr));
+                               F(p.dwPartEnc[1]), p.dwPartBytesEnc[1], &dfr, nullptr, nullptr, io1));
+        MVH_REQUIRE(fused || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the weight-gradient kernel");
         if (!fused) {
           TRY(mvh_pool_bwd(stream, &d->down_t[1], F(p.g_encP[1]), F(p.g_encA[1]), B, p.f[2]));
           TRY(cheb_conv_bwd_impl(main, &d->lap[1], &d->lap_t[1], xin1, P[ix.encW(1)], F(p.encA[1]), F(p.g_encA[1]),
@@ -526,10 +557,12 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       continue;
     }
     bool ok_dw = false, deferred = false;
-    TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]), TX(p.txEnc[0]),
+    TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encP[0]),
+                           bf ? nullptr : TX(p.txEnc[0]),
                            nullptr, G[ix.encW(0)], G[ix.encB(0)], B, p.Nn[0], p.f[0], p.f[1], d->K[0], MVH_ACT_RELU, sm,
                            p.scratch_bytes, nullptr, &d->down[0], &ok_dw, BITS(p.encBits[0]), nullptr, &red.e[red.n],
-                           F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred));
+                           F(p.dwPartEnc[0]), p.dwPartBytesEnc[0], &deferred, nullptr, nullptr, io));
+    MVH_REQUIRE(ok_dw || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the first layer's weight gradient");
     if (!ok_dw) {
       TRY(mvh_pool_bwd(stream, &d->down_t[0], F(p.g_encP[0]), F(p.g_encA[0]), B, p.f[1]));
       TRY(cheb_conv_bwd_impl(main, &d->lap[0], &d->lap_t[0], xin, P[ix.encW(0)], F(p.encA[0]), F(p.g_encA[0]), TX(p.txEnc[0]),

@@ -39,6 +39,7 @@ class VaeDesc(ctypes.Structure):
     """mvh_vae_desc_t"""
     _fields_ = [("n_layers", ctypes.c_int32), ("num_features", ctypes.c_int32), ("num_hidden", ctypes.c_int32),
                 ("num_classes", ctypes.c_int32), ("num_style", ctypes.c_int32), ("dropout_p", ctypes.c_float),
+                ("storage", ctypes.c_int32),
                 ("filters", ctypes.c_int32 * (VAE_MAX_LAYERS + 2)), ("K", ctypes.c_int32 * (VAE_MAX_LAYERS + 1)),
                 ("num_nodes", ctypes.c_int32 * (VAE_MAX_LAYERS + 1)),
                 ("lap", CsrStruct * (VAE_MAX_LAYERS + 1)), ("lap_t", CsrStruct * (VAE_MAX_LAYERS + 1)),
@@ -47,6 +48,7 @@ class VaeDesc(ctypes.Structure):
 
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
+STORAGE_F32, STORAGE_BF16 = 0, 1
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 
@@ -66,6 +68,8 @@ SIGNATURES = {
     "mvh_cheb_conv_bwd": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 6 + [_P, _Z]),
     "mvh_cheb_conv_fwd_signs": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 5 + [_P, _Z]),
     "mvh_cheb_conv_bwd_signs": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 5 + [_P, _Z]),
+    "mvh_cheb_conv_fwd_bf16": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _Z]),
+    "mvh_cheb_conv_bwd_bf16": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 7 + [_I] * 6 + [_P, _Z]),
     "mvh_linear_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F]),
     "mvh_linear_bwd": (ctypes.c_int, [_P] * 8 + [_I] * 4 + [_F, _P, _Z]),
     "mvh_vae_latent_fwd": (ctypes.c_int, [_P, _P, _P, _P, _F] + [_P] * 12 + [_I] * 4),

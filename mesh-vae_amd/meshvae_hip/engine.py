@@ -491,6 +491,8 @@ class NativeStep:
         d.n_layers, d.num_features = n, net.filters[0]
         d.num_hidden, d.num_classes, d.num_style = net.num_hidden, net.num_class, net.z
         d.dropout_p = float(net.dropout.p)
+        from . import STORAGE_BF16, STORAGE_F32
+        d.storage = STORAGE_BF16 if storage == "bf16" else STORAGE_F32
         for i, v in enumerate(net.filters):
             d.filters[i] = v
         for i in range(n + 1):

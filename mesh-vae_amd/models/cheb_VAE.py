@@ -231,7 +231,11 @@ class cheb_VAE(torch.nn.Module):
         """Native step object (descriptor, workspace, gradient buffers) for batch size B, a few sizes cached."""
         from meshvae_hip.engine import NativeStep
         cache = self.__dict__.setdefault("_fused_cache", {})
-        ent = cache.get(B)
+        # net.storage = "bf16": the fused forward / backward keep the activations between the conv layers as bf16
+        # (mvh_vae_desc_t.storage; fp32 accumulation, fp32 parameters) -- BASELINE configs[1] as worded.  Default fp32.
+        storage = getattr(self, "storage", "f32")
+        B_key = (B, storage)
+        ent = cache.get(B_key)
         if ent is None:
             if len(cache) >= 3:                      # (a workspace is ~12 MB per mesh: keep few batch sizes)
                 cache.pop(next(iter(cache)))
@@ -241,7 +245,8 @@ class cheb_VAE(torch.nn.Module):
             for p in params:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += -(-p.numel() // 64) * 64
-            ent = cache[B] = {"step": NativeStep(self, B, grads=views), "flat": flat, "views": views, "gen": 0}
+            ent = cache[B_key] = {"step": NativeStep(self, B, grads=views, storage=storage), "flat": flat, "views": views,
+                                  "gen": 0}
         ent["step"]._refresh_pointers()
         return ent
 
