@@ -157,10 +157,12 @@ def lds_kernel_name(kind, lap, N, Cin, Cout):
     return f"k_cheb_lds<{cq},{s[0]},{s[1]},{pw},{'true' if kind == 'dX' else 'false'}>"
 
 
-def conv_ops(net, B, dev):
+def conv_ops(net, B, dev, dtype="f32"):
     """One entry per (conv layer, fwd | dX | dW) of the model: a closure that launches it through the C ABI as the
     public fused-ReLU ops do, its algorithmic bytes (every operand read or written exactly once: DESIGN.md 4) and
-    the name of the kernel instance that dominates it."""
+    the name of the kernel instance that dominates it.  dtype "bf16": layers whose channel counts are multiples of 4
+    run the bf16-storage ops (mvh_cheb_conv_*_bf16); the 3-channel first / final layers keep fp32 tensors here (in
+    the step only their 16-channel side is bf16)."""
     from meshvae_hip import check, lib
     L = lib()
     net._prepare()
@@ -179,12 +181,16 @@ def conv_ops(net, B, dev):
                for _, _, N, Cin, Cout, K, _, _ in layers)
     ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)   # one scratch buffer: the ops run one after the other
     for label, lap, N, Cin, Cout, K, relu, has_dx in layers:
-        x = torch.randn(B, N, Cin, device=dev)
-        out = torch.empty(B, N, Cout, device=dev)
-        dout = torch.randn(B, N, Cout, device=dev)
+        half = dtype == "bf16" and Cin % 4 == 0 and Cout % 4 == 0
+        td = torch.bfloat16 if half else torch.float32
+        esize = 2 if half else 4
+        x = torch.randn(B, N, Cin, device=dev).to(td)
+        out = torch.empty(B, N, Cout, device=dev, dtype=td)
+        dout = torch.randn(B, N, Cout, device=dev).to(td)
         W = torch.randn(K, Cin, Cout, device=dev) * 0.1
         bias = torch.zeros(Cout, device=dev) if relu else None
         dW, dx = torch.empty_like(W), torch.empty_like(x)
+        act = 1 if relu else 0
         db = torch.empty(Cout, device=dev) if relu else None
         use_signs = relu and Cout % 4 == 0 and K > 1
         signs = torch.empty(B, N, max(Cout // 4, 1), dtype=torch.uint8, device=dev)
@@ -192,8 +198,11 @@ def conv_ops(net, B, dev):
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
         def fwd(lap=lap, x=x, W=W, bias=bias, out=out, signs=signs, N=N, Cin=Cin, Cout=Cout, K=K, ws=ws, ws_b=ws_b,
-                use_signs=use_signs, relu=relu):
-            if use_signs:
+                use_signs=use_signs, relu=relu, half=half, act=act):
+            if half:
+                check(L.mvh_cheb_conv_fwd_bf16(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(signs) if relu else None, B, N,
+                                               Cin, Cout, K, act, p(ws), ws_b))
+            elif use_signs:
                 check(L.mvh_cheb_conv_fwd_signs(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(signs), B, N, Cin, Cout,
                                                 K, p(ws), ws_b))
             else:
@@ -201,23 +210,30 @@ def conv_ops(net, B, dev):
                                           int(relu), p(ws), ws_b))
 
         def bwd(want_dx, want_dw, lap=lap, x=x, W=W, out=out, signs=signs, dout=dout, dx=dx, dW=dW, db=db, N=N, Cin=Cin,
-                Cout=Cout, K=K, ws=ws, ws_b=ws_b, use_signs=use_signs, relu=relu):
+                Cout=Cout, K=K, ws=ws, ws_b=ws_b, use_signs=use_signs, relu=relu, half=half, act=act):
             a_dx, a_dw, a_db = (p(dx) if want_dx else None), (p(dW) if want_dw else None), (p(db) if want_dw else None)
-            if use_signs:
+            if half:
+                check(L.mvh_cheb_conv_bwd_bf16(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(signs) if relu else None, p(dout),
+                                               a_dx, a_dw, a_db, B, N, Cin, Cout, K, act, p(ws), ws_b))
+            elif use_signs:
                 check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(signs), p(dout), a_dx,
                                                 a_dw, a_db, B, N, Cin, Cout, K, p(ws), ws_b))
             else:
                 check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(dout), None, a_dx, a_dw,
                                           a_db, B, N, Cin, Cout, K, int(relu), p(ws), ws_b))
         fwd()                                    # forward once: valid `out` / signs for the backward closures
-        pin, pout = B * N * Cin * 4, B * N * Cout * 4
-        sb = B * N * (Cout // 4) if use_signs else (pout if relu else 0)      # ReLU mask: sign bytes, else the fp32 output
-        desc = f"{label} N={N} {Cin}->{Cout} K={K}"
+        pin, pout = B * N * Cin * esize, B * N * Cout * esize
+        sb = B * N * (Cout // 4) if (use_signs or (half and relu)) else (pout if relu else 0)   # ReLU mask: sign bytes, else the fp32 output
+        desc = f"{label} N={N} {Cin}->{Cout} K={K}" + (" bf16" if half else "")
         ops.append(dict(op=f"conv fwd {desc}", kernel=lds_kernel_name("fwd", lap, N, Cin, Cout), fn=fwd,
-                        bytes=pin + pout + (B * N * (Cout // 4) if use_signs else 0), keep=keep))
+                        bytes=pin + pout + (B * N * (Cout // 4) if (use_signs or (half and relu)) else 0), keep=keep))
         if has_dx:
             ops.append(dict(op=f"conv dX {desc}", kernel=lds_kernel_name("dX", lap, N, Cin, Cout),
                             fn=lambda bwd=bwd: bwd(True, False), bytes=pout + sb + pin, keep=keep))
+        if label == "enc0" and lds_kernel_name("fwd", lap, N, Cin, Cout) is not None:
+            # the step takes this layer's weight gradient from a saved Chebyshev stack at the pooled rows
+            # (k_cheb_tstack + k_stack_dw, csrc/cheb_tstack.hip), which the public per-layer op cannot express
+            continue
         ops.append(dict(op=f"conv dW {desc}", kernel=lds_kernel_name("dW", lap, N, Cin, Cout),
                         fn=lambda bwd=bwd: bwd(False, True), bytes=pin + pout + sb, keep=keep))
     return ops
@@ -227,7 +243,7 @@ def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "d
     """The `roofline` object of the bench line: the conv launch that costs the step most, by the rocprofv3 total-time
     ranking of the committed profile taken on these sources when there is one (profiles/<tag>_kernel_stats.csv),
     otherwise by the live isolated timings; `achieved` always comes from the live HIP-event average."""
-    ops = [o for o in conv_ops(net, B, dev) if o["op"].split()[1] in kinds]
+    ops = [o for o in conv_ops(net, B, dev, dtype) if o["op"].split()[1] in kinds]
     for o in ops:
         o["ms"] = time_kernel(o["fn"])
     tag, pmc, stats = matching_profile(config, dtype)

@@ -90,7 +90,7 @@ int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
 /* Debug / A-B switches (no reference counterpart).  They live in ONE struct that is filled when the
  * library is loaded from MESHVAE_DEBUG="key=value,..." and is never re-read from the environment;
  * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch,
- * no_gstack_mfma, no_dw_mfma, no_xcd_remap.  mvh_debug_set changes one switch in-process (the tests
+ * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch.  mvh_debug_set changes one switch in-process (the tests
  * run both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
 int mvh_debug_set(const char* key, int32_t value);
 int32_t mvh_debug_get(const char* key);
@@ -327,6 +327,13 @@ int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const floa
                      const float* eps, const float* drop_u, int32_t B, float log_sigma, const void* d_loss,
                      const float* recon, const float* y_hat, const float* mu, const float* logvar,
                      void* ws, size_t ws_bytes, mvh_stream_t side_stream /* NULL = internal */);
+/* Optional, BEFORE mvh_vae_forward of a step whose backward will follow (same x, ws, side_stream, same host thread):
+ * starts the input-only part of the backward -- T_k(L) x of the first layer at the rows its pooling keeps, what
+ * autograd would recompute from x at main.py:80 -- on the weight-gradient lane, forked from `stream` with an event;
+ * mvh_vae_backward then only waits for it.  A forward with no backward after it must not be preceded by this call
+ * inside a stream capture (the fork would stay unjoined).  No effect on results. */
+int mvh_vae_backward_prefetch(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* x, int32_t B,
+                              void* ws, size_t ws_bytes, mvh_stream_t side_stream /* NULL = internal */);
 
 /* The two halves of the forward on their own, for the inference-side callers that use the model piecewise
  * (inference.py:98-131, crecon.py:167-192: net.encoder(x) ... net.sample(y, z)): the same launch sequences as inside

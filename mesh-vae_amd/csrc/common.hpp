@@ -52,6 +52,7 @@ struct DebugCfg {
   int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
   int no_dw_mfma = 0;
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
+  int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
 };
 DebugCfg& dbg();
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mvh_vae_param_count": (ctypes.c_int32, [ctypes.POINTER(VaeDesc)]),
     "mvh_vae_forward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
     "mvh_vae_backward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z, _P]),
+    "mvh_vae_backward_prefetch": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _I, _P, _Z, _P]),
     "mvh_vae_loss_bwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 4),
 }
 

@@ -590,6 +590,9 @@ class NativeStep:
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         with torch.cuda.device(self.dev):
             st = torch.cuda.current_stream(self.dev).cuda_stream
+            if backward:     # the input-only part of the backward runs underneath the forward
+                check(L.mvh_vae_backward_prefetch(st, d, x.data_ptr(), self.B, self.ws.data_ptr(), self.ws_bytes,
+                                                  self.side.cuda_stream if self.side is not None else None))
             check(L.mvh_vae_forward(st, d, self._P, x.data_ptr(), y_f.data_ptr(), x_gt.data_ptr(), f64, ptr(eps),
                                     ptr(drop_u), self.B, self.log_sigma, loss.data_ptr(), self.correct.data_ptr(),
                                     self.recon.data_ptr(), self.kld.data_ptr(), rec.data_ptr(), self.z_.data_ptr(),

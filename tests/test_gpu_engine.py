@@ -362,8 +362,11 @@ def test_dense_gradients_are_final_at_the_library_event():
         with torch.cuda.stream(comm):
             snap.copy_(flat.grad[split:])
         torch.cuda.synchronize()
-        for p, off in zip(flat.params[k:], flat.offsets[k:]):
+        for name, p, off in zip(flat.names[k:], flat.params[k:], flat.offsets[k:]):
             got = snap[off - split:off - split + p.numel()]
+            if name.startswith("dec_lin_1."):      # no gradient exists for it (cheb_VAE.py:165): the span is never written
+                assert not torch.isfinite(got).any()
+                continue
             assert torch.isfinite(got).all(), "dense gradient read before it was written"
             assert torch.equal(got, p.grad.reshape(-1))
         for p in flat.params[:k]:
@@ -545,7 +548,7 @@ def test_bench_line_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["config"]["workload"].startswith("configs[1]")
     assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
-    assert len(d["kernels"]) == 26                       # 9 conv layers x (fwd, dX, dW) minus the first layer's dX
+    assert len(d["kernels"]) == 25                       # 9 conv layers x (fwd, dX, dW) minus the first layer's dX and dW
 
 
 def test_bench_infer_line_contract():
