@@ -342,6 +342,11 @@ class TrainStep:
         self.eps.copy_(buf, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
 
+    # MEASURED, not kept (round 2): drawing step t+1's noise (pinned copy + dropout uniforms) one step ahead on a stream
+    # of its own, double-buffered, so that the step boundary on the main stream is Adam -> weight pack -> first
+    # convolution: 598 vs 590 us per step in three alternating runs -- the fourth stream costs more (hardware-queue
+    # sharing) than the ~15 us of copy / generator kernels it takes off the boundary.
+
     def set_epoch(self, config, epoch):
         """Apply the reference's LR table for `epoch` (main.py:266-269).  The rate is a kernel argument of the
         fused Adam launch, so it takes effect on the next eager step; a captured optimizer graph is re-captured."""
