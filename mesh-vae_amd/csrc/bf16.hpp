@@ -39,4 +39,16 @@ __device__ __forceinline__ float load1_any(const float* base, long long idx, boo
   return base[idx];
 }
 
+__host__ __device__ inline int l0h_pack_dwords_hd(int K) { return 4 * K * 32; }
+// dword i of the bf16 weight slabs of the level-0 matrix-pipe kernel (cheb_l0h.hip): Wh[slab][k][cg][i][d], one
+// dword = the two input channels 4 cg + 2 d (low half) and + 1 (high half) of output channel 4 slab + i --
+// W[k][c][o] forward, W[k][o][c] backward (W^T); 16 channels on both sides.
+__device__ __forceinline__ uint32_t pack_l0h_dword(const float* __restrict__ W, int K, int bwd, int i) {
+  const int d = i & 1, oi = (i >> 1) & 3, cg = (i >> 3) & 3, k = (i >> 5) % K, sl = (i >> 5) / K;
+  const int o = sl * 4 + oi, c = cg * 4 + 2 * d;
+  const float w0 = bwd ? W[((long long)k * 16 + o) * 16 + c] : W[((long long)k * 16 + c) * 16 + o];
+  const float w1 = bwd ? W[((long long)k * 16 + o) * 16 + c + 1] : W[((long long)k * 16 + c + 1) * 16 + o];
+  return bf16_pack2(w0, w1);
+}
+
 }  // namespace mvh

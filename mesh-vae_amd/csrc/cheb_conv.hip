@@ -785,7 +785,7 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
     LdsConvOpts fo;
     fo.prepacked = prepacked;
-    fo.in_bf16 = io.x; fo.out_bf16 = io.out; fo.pooled_bf16 = io.pooled;
+    fo.in_bf16 = io.x; fo.out_bf16 = io.out; fo.pooled_bf16 = io.pooled; fo.prepacked_h = io.wh;
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
     fo.bits_out = bits_out;
     bool pooled_in_kernel = fo.pool_inv != nullptr;
@@ -1016,7 +1016,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     LdsConvOpts bo;
     bo.prepacked = prepacked_bwd;
     bo.mask_bits = out_bits;
-    bo.in_bf16 = io.dout;
+    bo.in_bf16 = io.dout; bo.prepacked_h = io.wh;
     if (dx_pool_t && dx_pooled) {  // pooled rows straight from the kernel (dx itself is not materialised)
       bo.out_pool_t = dx_pool_t;
       bo.out_bf16 = io.dx_pooled;

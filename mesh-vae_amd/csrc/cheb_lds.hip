@@ -545,6 +545,10 @@ __global__ void __launch_bounds__(256) k_pack_all(PackTable t) {
   const PackEntry e = t.e[blockIdx.y];
   const int NS = (e.CO + 3) >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e.bwd >= 3) {  // bf16 slabs of the level-0 matrix-pipe kernel
+    if (i < l0h_pack_dwords_hd(e.K)) reinterpret_cast<uint32_t*>(e.dst)[i] = pack_l0h_dword(e.W, e.K, e.bwd == 4, i);
+    return;
+  }
   if (e.bwd == 2) {  // W_eff = sum_k T_k(0) W_k (isolated vertices of the split path): T_k(0) = 1, 0, -1, 0, ...
     if (i >= e.Cin * e.Cout) return;
     float s = 0.f;
@@ -570,7 +574,8 @@ int launch_pack_all(hipStream_t st, const PackTable& t) {
   if (t.n == 0) return MVH_OK;
   int mx = 0;
   for (int i = 0; i < t.n; ++i) {
-    const int nf = t.e[i].bwd == 2 ? t.e[i].Cin * t.e[i].Cout : ((t.e[i].CO + 3) / 4) * t.e[i].K * t.e[i].CQ * 4;
+    const int nf = t.e[i].bwd >= 3 ? l0h_pack_dwords(t.e[i].K)
+                   : t.e[i].bwd == 2 ? t.e[i].Cin * t.e[i].Cout : ((t.e[i].CO + 3) / 4) * t.e[i].K * t.e[i].CQ * 4;
     if (nf > mx) mx = nf;
   }
   hipLaunchKernelGGL(k_pack_all, dim3(cdiv(mx, 256), t.n), dim3(256), 0, st, t);
@@ -622,6 +627,10 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack, bool* handled, const LdsConvOpts& o) {
   *handled = false;
+  if (o.in_bf16) {  // the 5k level's 16 -> 16 layer on bf16 rows: packed registers + matrix-pipe contraction
+    if (int rc = try_cheb_l0h(st, lap, in, o.mask_bits, W, bias, out, B, N, Cin, Cout, K, act, bwd, wpack, handled, o)) return rc;
+    if (*handled) return MVH_OK;
+  }
   const float* prepacked = o.prepacked;
   if (!wpack && !prepacked) return MVH_OK;
   if (dbg().force_generic) return MVH_OK;

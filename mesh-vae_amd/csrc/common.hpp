@@ -53,6 +53,7 @@ struct DebugCfg {
   int no_dw_mfma = 0;
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
   int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
+  int no_l0h = 0;          // bf16 storage: keep the unpack-and-v_fma form at the 5k level (no cheb_l0h.hip kernel)
 };
 DebugCfg& dbg();
 
@@ -96,17 +97,28 @@ struct LdsConvOpts {
   // bf16 STORAGE of the activation tensors (bf16.hpp): `in`, `out` (backward with out_pool_t: the pooled buffer) and
   // `pooled` are then 2-byte tensors behind the float pointers; arithmetic and the LDS state stay fp32
   bool in_bf16 = false, out_bf16 = false, pooled_bf16 = false;
+  const uint32_t* prepacked_h = nullptr;   // bf16 weight slabs of cheb_l0h.hip already built (launch_pack_all)
 };
+// level-0 16 -> 16 forward / dX on bf16 rows with the contraction on the matrix pipe (cheb_l0h.hip)
+int try_cheb_l0h(hipStream_t st, const mvh_csr_t* lap, const float* in, const uint8_t* mask_bits, const float* W,
+                 const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd, void* wpack,
+                 bool* handled, const LdsConvOpts& o);
+int l0h_pack_dwords(int K);
+// ... and its weight gradient (cheb_dw_l0h.hip)
+int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
+                    float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
+                    bool* handled, bool dry_run, DwReduceEntry* defer);
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled, const LdsConvOpts& o = LdsConvOpts());
 struct PackEntry {
   const float* W;
   float* dst;
-  int K, Cin, Cout, CQ, CO, bwd;  // bwd: 0 forward slabs, 1 W^T slabs, 2 = W_eff [Cin*Cout] of the split path
+  int K, Cin, Cout, CQ, CO, bwd;  // bwd: 0 forward slabs, 1 W^T slabs, 2 = W_eff [Cin*Cout] of the split path,
+                                  //      3 / 4 = bf16 slabs of cheb_l0h.hip, forward / W^T (16 -> 16 only)
 };
 struct PackTable {
-  PackEntry e[2 * (MVH_VAE_MAX_LAYERS * 2 + 1) + 1];
+  PackEntry e[2 * (MVH_VAE_MAX_LAYERS * 2 + 1) + 3];
   int n;
 };
 int pack_entry_floats(int Cin, int Cout, int K, bool bwd);
@@ -117,6 +129,8 @@ int launch_pack_all(hipStream_t st, const PackTable& t);
 struct ConvIO {
   bool x = false, out = false, pooled = false;          // forward: input, output, fused-pooling output
   bool dout = false, dx = false, dx_pooled = false;     // backward: output gradient, input gradient, its pooled form
+  const uint32_t* wh = nullptr;                         // bf16 weight slabs of cheb_l0h.hip for this call (forward
+                                                        // layout in the forward, W^T layout in the backward) or null
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)

@@ -15,6 +15,8 @@ struct Buf {
   size_t off;  // byte offset into the workspace
 };
 
+constexpr size_t kNoBits = ~(size_t)0;
+
 struct StepPlan {
   int n, B, H, C, Z, F0, flat;
   std::vector<int> Nn;            // vertices per level [n+1]
@@ -28,12 +30,11 @@ struct StepPlan {
   std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
   size_t tstack;                         // T_k x of layer 0 at the rows its pooling selects (+ dW partials)
   size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
+  size_t pk_h_f, pk_h_b;                 // bf16 weight slabs of the level-0 matrix-pipe kernel (cheb_l0h.hip), or kNoBits
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   std::vector<size_t> txEnc, txDec;      // saved T_1..T_{K-1} stacks of the levels too big for the LDS kernels
   size_t total;
 };
-
-constexpr size_t kNoBits = ~(size_t)0;
 
 static size_t take(size_t& cur, size_t floats) {
   const size_t o = cur;
@@ -89,6 +90,11 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.pk_dec_f[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], false));
   p.pk_dec_b[n] = take(cur, pack_entry_floats(p.f[1], p.f[0], d->K[n], true));
   p.weff_final = take(cur, (size_t)p.f[1] * p.f[0]);
+  p.pk_h_f = p.pk_h_b = kNoBits;
+  if (d->storage == MVH_STORAGE_BF16 && p.f[2] == 16 && p.f[1] == 16) {   // last decoder stage: f[2] -> f[1] at level 0
+    p.pk_h_f = take(cur, l0h_pack_dwords(d->K[n - 1]));
+    p.pk_h_b = take(cur, l0h_pack_dwords(d->K[n - 1]));
+  }
   p.tstack = take(cur, tstack_ws_floats(B, p.Nn[0], d->K[0], p.f[0], p.f[1]));
   p.dwPartEnc.resize(n); p.dwPartDec.resize(n); p.dwPartBytesEnc.resize(n); p.dwPartBytesDec.resize(n);
   for (int i = 0; i < n; ++i) {
@@ -249,6 +255,12 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     add(P[ix.decW(n)], p.pk_dec_b[n], p.f[1], p.f[0], d->K[n], true);
     add(P[ix.decW(n)], p.weff_final, p.f[1], p.f[0], d->K[n], false);
     t.e[t.n - 1].bwd = 2;
+    if (p.pk_h_f != kNoBits) {  // bf16 slabs for the matrix-pipe kernel of the last decoder stage (forward, W^T)
+      add(P[ix.decW(n - 1)], p.pk_h_f, p.f[2], p.f[1], d->K[n - 1], false);
+      t.e[t.n - 1].bwd = 3;
+      add(P[ix.decW(n - 1)], p.pk_h_b, p.f[2], p.f[1], d->K[n - 1], true);
+      t.e[t.n - 1].bwd = 4;
+    }
     TRY(launch_pack_all((hipStream_t)stream, t));
   }
   // ---- encoder (cheb_VAE.py:261-273)
@@ -285,6 +297,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     const bool more = i + 1 < n;
     ConvIO io;
     io.x = io.out = io.pooled = bf;
+    if (i == n - 1 && p.pk_h_f != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_f));
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
                            bf ? nullptr : TX(p.txDec[i]), B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes,
                            F(p.pk_dec_f[i]), more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr,
@@ -493,6 +506,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     ConvIO io;
     io.x = io.dout = io.dx = bf;
     io.dx_pooled = bf && i > 0;   // (stage 0 hands its pooled gradient to the fp32 dense head)
+    if (i == n - 1 && p.pk_h_b != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_b));
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
                      p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));

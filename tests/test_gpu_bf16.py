@@ -4,7 +4,8 @@ nn/conv.py:557-577, nn/pool.py:17-20.
 
 Tolerances, and why.  bfloat16 keeps 8 significant bits: one round-to-nearest store moves a value by at most
 2^-9 = 0.195 % of its magnitude.
-  * Layer level: the oracle runs in fp32 on the SAME bf16-rounded inputs, so an output differs from it only by its
+  * Layer level: the oracle runs in fp32 on the SAME bf16-rounded inputs (and, for the one layer shape whose products
+    run on the bf16 matrix pipe, the same bf16-rounded weight copy), so an output differs from it only by its
     own final rounding (<= 2^-9 relative, + the fp32 noise the 1e-4 tests already allow); weight / bias gradients
     are fp32 outputs of fp32 sums over identical inputs and keep the fp32 bar.
   * Whole model: x -> recon crosses 9 convolutions and 8 pools, each rounding its result once: measured on MI355X
@@ -68,9 +69,12 @@ def test_bf16_conv_ops_match_the_oracle_on_rounded_inputs(topo, level, B, Cin, C
     dout = torch.randn(B, N, Cout, generator=g).to(torch.bfloat16)
     W = torch.randn(K, Cin, Cout, generator=g) * 0.1
     bias = torch.randn(Cout, generator=g) * 0.1 if relu else None
+    # the 5k level's 16 -> 16 layer multiplies on the matrix pipe (csrc/cheb_l0h.hip): bf16 x bf16 products of the
+    # stored activations with a bf16 COPY of the fp32 weights, fp32 sums -- the oracle gets the same rounded weights
+    W_used = W.to(torch.bfloat16).float() if (N + 1 > 2048 and Cin == 16 and Cout == 16) else W
     # oracle: fp32 arithmetic on the SAME (already rounded) inputs
     xo = x.float().requires_grad_(True)
-    Wo = W.clone().requires_grad_(True)
+    Wo = W_used.clone().requires_grad_(True)
     bo = bias.clone().requires_grad_(True) if relu else None
     yo = O.cheb_conv(xo, ei, nrm, Wo, bo)
     if relu:
@@ -107,7 +111,9 @@ def test_bf16_conv_ops_match_the_oracle_on_rounded_inputs(topo, level, B, Cin, C
     errx = (dx.float().cpu() - gx).abs()
     assert float((errx - 2 * BF16_EPS * gx.abs()).max()) < 5e-5 * max(float(gx.abs().max()), 1.0), float(errx.max())
     rel_w = float((dW.cpu() - Wo.grad).norm() / Wo.grad.norm())
-    assert rel_w < 1e-4, rel_w                                   # fp32 sums over identical inputs
+    # fp32 sums over identical inputs; on the bf16 matrix pipe (the 5k level's 16 -> 16 layer, csrc/cheb_dw_l0h.hip) T_k(x)
+    # is rounded to bf16 for the products: independent relative errors <= 2^-9 per term
+    assert rel_w < (3e-3 if W_used is not W else 1e-4), rel_w
     if relu:
         torch.testing.assert_close(db.cpu(), bo.grad, rtol=1e-4, atol=1e-4 * float(bo.grad.abs().max()))
     # unsupported shapes fail loudly instead of falling back to another precision
