@@ -590,7 +590,7 @@ constexpr size_t kSplitScratchBytes = 64 * 1024;
 // A streaming reduction (HBM-bound): QV = CX/4 lanes share a row, each holding 16 B of x and the
 // CD dpre values; lanes with the same channel quad are summed with shuffles, waves through LDS,
 // blocks through `partial` [grid][(CX + 1) * CD] and a one-block finish (fixed order).
-constexpr int kXtyGrid = 1024;
+constexpr int kXtyGrid = 256;   // (1024 partial sets made the one-block finish 16 us: 51 dependent loads per thread)
 
 template <int CD>
 __global__ void __launch_bounds__(256)
@@ -951,7 +951,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   const bool split_ok = !tx_saved && split_eligible(lap, N, Cin, Cout, K) && split_eligible(lap_t, N, Cin, Cout, K);
   const int CC = Cin * Cout;
   if (split_ok && !dw_done) {  // dW_k = dWsub_k + c_k (S_all - dWsub_0), see k_dw_combine
-    float* S = split + CC;                 // [CC]
+    float* S = (defer && io.s_keep) ? io.s_keep : split + CC;   // [CC]
     float* dWsub = split + 2 * CC;         // [K][CC]
     const size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);
     const float* mask = act == MVH_ACT_RELU ? out : nullptr;
@@ -961,10 +961,22 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     if (!h1)
       if (int rc = try_cheb_dw_lds(st, lap, x, dout, mask, S, db, B, N, Cin, Cout, 1, partial, pbytes, &h1, 0, nullptr, 0,
                                    false, out_bits, nullptr, io.x, io.dout)) return rc;
-    if (h1)
+    if (h1 && defer && io.s_keep && !db) {
+      // deferred form: the connected block's partial tiles stay in the caller's buffer and launch_dw_reduce_all
+      // applies dW_k = dWsub_k + T_k(0) (S - dWsub_0) itself (two launches less on the weight-gradient lane)
+      if (int rc = try_cheb_dw_lds(st, lap->sub, x, dout, mask, dW, nullptr, B, lap->n_active, Cin, Cout, K, defer_part,
+                                   defer_bytes, &h2, N, nullptr, 0, false, out_bits, defer, io.x, io.dout)) return rc;
+      if (h2) {
+        defer->S = S;
+        *deferred = true;
+        dw_done = true;
+        h1 = false;   // (nothing left for the immediate form below)
+      }
+    }
+    if (h1 && !dw_done)
       if (int rc = try_cheb_dw_lds(st, lap->sub, x, dout, mask, dWsub, nullptr, B, lap->n_active, Cin, Cout, K, partial,
                                    pbytes, &h2, N, nullptr, 0, false, out_bits, nullptr, io.x, io.dout)) return rc;
-    if (h1 && h2) {
+    if (h1 && h2 && !dw_done) {
       hipLaunchKernelGGL(k_dw_combine, dim3(cdiv(K * CC, 256)), dim3(256), 0, st, dW, dWsub, S, K, CC);
       MVH_LAUNCH_CHECK();
       dw_done = true;

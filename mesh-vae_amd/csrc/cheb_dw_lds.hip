@@ -496,12 +496,14 @@ __device__ __forceinline__ void dw_reduce_body(const DwReduceEntry& t, int block
             db_mode = t.db_mode;
   float* __restrict__ dW = t.dW;
   float* __restrict__ db = t.db;
+  const float* __restrict__ S = t.S;
   __shared__ float red[16][64];
+  __shared__ float red0[16][64];   // split path: the order-0 sums of the same (q, j)
   const int tile = (K + 1) * CQ * 4;  // floats per (slab, mesh, wave)
   const int n_out = NS * tile;
   const int lo = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int o = block * 64 + lo;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, z0 = 0.f;
   if (o < n_out) {
     const int sl = o / tile, e = o - sl * tile;
     const float* src = part + (long long)sl * n_part * tile + e;
@@ -513,19 +515,31 @@ __device__ __forceinline__ void dw_reduce_body(const DwReduceEntry& t, int block
       s3 += src[(long long)(p + 48) * tile];
     }
     for (; p < n_part; p += 16) s0 += src[(long long)p * tile];
+    if (S) {  // the order-0 entry of the same (q, j): e0 = e mod (CQ * 4)
+      const float* src0 = part + (long long)sl * n_part * tile + (e % (CQ * 4));
+      for (int p2 = grp; p2 < n_part; p2 += 16) z0 += src0[(long long)p2 * tile];
+    }
   }
   red[grp][lo] = (s0 + s1) + (s2 + s3);
+  red0[grp][lo] = z0;
   __syncthreads();
   if (grp != 0 || o >= n_out) return;
-  float s = 0.f;
+  float s = 0.f, sz = 0.f;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) s += red[g][lo];
+  for (int g = 0; g < 16; ++g) {
+    s += red[g][lo];
+    sz += red0[g][lo];
+  }
   const int sl = o / tile, e = o - sl * tile;
   const int k = e / (CQ * 4), q = (e / 4) % CQ, j = e & 3;
   const int p = sl * 4 + j;
   if (k < K) {
     if (p >= CP) return;
     const int ci = p_is_x ? p : q, co = p_is_x ? q : p;
+    if (S) {
+      const float ck = (k & 1) ? 0.f : ((k & 2) ? -1.f : 1.f);   // T_k(0)
+      s += ck * (S[ci * Cout + co] - sz);
+    }
     dW[((long long)k * Cin + ci) * Cout + co] = s;
   } else if (db) {
     if (db_mode == 1 && sl == 0 && j == 0) db[q] = s;  // Q = dpre: db[co = q]

@@ -72,6 +72,9 @@ struct DwReduceEntry {
   int n_part, NS, K, CQ, CP, p_is_x, Cin, Cout, db_mode;
   float* dW;
   float* db;
+  // split path (mostly-isolated Laplacian, cheb_conv.hip): `part` holds the tiles of the CONNECTED block only and
+  // dW_k = dWsub_k + T_k(0) (S - dWsub_0) with S = sum over ALL rows of x^T dpre [Cin][Cout]; null = plain sum
+  const float* S = nullptr;
 };
 struct DwReduceTable {
   DwReduceEntry e[2 * MVH_VAE_MAX_LAYERS + 1];
@@ -131,6 +134,8 @@ struct ConvIO {
   bool dout = false, dx = false, dx_pooled = false;     // backward: output gradient, input gradient, its pooled form
   const uint32_t* wh = nullptr;                         // bf16 weight slabs of cheb_l0h.hip for this call (forward
                                                         // layout in the forward, W^T layout in the backward) or null
+  float* s_keep = nullptr;                              // split path + deferred reduction: where S [Cin*Cout] may stay
+                                                        // until launch_dw_reduce_all (the scratch is reused before)
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)

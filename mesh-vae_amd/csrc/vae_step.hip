@@ -30,6 +30,7 @@ struct StepPlan {
   std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
   size_t tstack;                         // T_k x of layer 0 at the rows its pooling selects (+ dW partials)
   size_t weff_final;                     // W_eff of the final layer (split path), built with the packs
+  size_t dwPartFinal, dwPartBytesFinal, s_final;   // final layer (split path): partial tiles of its connected block, S
   size_t pk_h_f, pk_h_b;                 // bf16 weight slabs of the level-0 matrix-pipe kernel (cheb_l0h.hip), or kNoBits
   std::vector<size_t> encBits, decBits;  // ReLU sign bytes of the conv outputs (kNoBits when Cout % 4 != 0)
   std::vector<size_t> txEnc, txDec;      // saved T_1..T_{K-1} stacks of the levels too big for the LDS kernels
@@ -103,6 +104,9 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
     p.dwPartBytesDec[i] = cheb_dw_lds_ws_bytes(B, p.Nn[n - i - 1], p.f[n + 1 - i], p.f[n - i], d->K[i]);
     p.dwPartDec[i] = take(cur, p.dwPartBytesDec[i] / sizeof(float) + 1);
   }
+  p.dwPartBytesFinal = cheb_dw_lds_ws_bytes(B, p.Nn[0], p.f[1], p.f[0], d->K[n]);
+  p.dwPartFinal = take(cur, p.dwPartBytesFinal / sizeof(float) + 1);
+  p.s_final = take(cur, (size_t)p.f[1] * p.f[0]);
   p.encBits.assign(n, kNoBits); p.decBits.assign(n, kNoBits);
   for (int i = 0; i < n; ++i) {  // one byte per vertex and 4 output channels
     if (p.f[i + 1] % 4 == 0) p.encBits[i] = take(cur, ((size_t)B * p.Nn[i] * (p.f[i + 1] / 4) + 3) / 4);
@@ -495,8 +499,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     const float* xin = F(p.decC[n - 1]);
     ConvIO io;
     io.x = bf; io.dx = bf;   // (g_recon is fp32)
+    io.s_keep = F(p.s_final);
     TRY(conv_dw_side(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), G[ix.decW(n)], nullptr,
-                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr, io));
+                     p.Nn[0], p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, nullptr, io, p.dwPartFinal, p.dwPartBytesFinal));
     TRY(conv_dx_main(&d->lap[n], &d->lap_t[n], xin, P[ix.decW(n)], nullptr, F(p.g_recon), F(p.g_decC[n - 1]), p.Nn[0],
                      p.f[1], p.f[0], d->K[n], MVH_ACT_NONE, p.pk_dec_b[n], nullptr, io, F(p.weff_final)));
   }
