@@ -29,4 +29,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONF
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python3 bench.py $SHORT > "$OUT/pmc_$name.log" 2>&1 || echo "pmc $name FAILED (see log)"
   echo "pmc $name done"
 done
-python tools/pmc_fold.py "$OUT" "$TAG" "$OUT" "$CONFIG" "$DTYPE"   # (re-run locally with profiles/ as destination)
+python tools/pmc_fold.py "$OUT" "$TAG" "$OUT" "$CONFIG" "$DTYPE"
+# gpurun copies at most 64 MiB back: keep the folded tables (copy them into profiles/), drop the raw rocprofv3 output
+[ -n "$KEEP_RAW" ] || rm -rf "$OUT"/stats "$OUT"/pmc_*/
