@@ -102,7 +102,7 @@ static int launch_contract(hipStream_t st, const float* x, const float* tx, cons
                            const float* bias, float* out, long long rows, int Cin, int Cout, int K,
                            int act, bool x_bf16 = false) {
   const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
-  if (x_bf16 && (!vin || K != 1 || Cin == 16 && Cout == 16))
+  if (x_bf16 && (!vin || K != 1 || (Cin == 16 && Cout == 16)))
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 rows reach the contraction only through the K = 1 split pass");
   const int xb = x_bf16 ? 1 : 0;
   const int grid = cdiv(rows, 256);

@@ -239,7 +239,7 @@ int try_cheb_l0h(hipStream_t st, const mvh_csr_t* lap, const float* in, const ui
   if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 4 || (lap->flags & need) != need) return MVH_OK;
   if (lap->flags & MVH_CSR_ELL_OVERFLOW) return MVH_OK;
   if (Cin != 16 || Cout != 16 || K < 1 || N + 1 > kL0hSlots || N + 1 <= 2048) return MVH_OK;   // the 5k level only
-  if (!o.in_bf16 || o.in_map || o.pool_inv || o.in_bs > 0 && o.in_bs != N) return MVH_OK;
+  if (!o.in_bf16 || o.in_map || o.pool_inv || (o.in_bs > 0 && o.in_bs != N)) return MVH_OK;
   if (bwd && mask_bits == nullptr && act == MVH_ACT_RELU) return MVH_OK;
   if (!wpack && !o.prepacked_h) return MVH_OK;
   if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)o.pooled) % 16 != 0) return MVH_OK;

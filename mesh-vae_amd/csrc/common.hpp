@@ -54,6 +54,7 @@ struct DebugCfg {
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
   int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
   int no_l0h = 0;          // bf16 storage: keep the unpack-and-v_fma form at the 5k level (no cheb_l0h.hip kernel)
+  int no_mid = 0;          // the small-level sub-networks stay per-layer launches (no cheb_mid.hip kernel)
 };
 DebugCfg& dbg();
 
@@ -111,6 +112,11 @@ int l0h_pack_dwords(int K);
 int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, bool dry_run, DwReduceEntry* defer);
+// decoder levels <= 384 vertices as one launch: unpool, conv + ReLU, unpool, conv + ReLU, unpool (cheb_mid.hip)
+int try_mid_dec_fwd(hipStream_t st, const mvh_csr_t* up3, const mvh_csr_t* lap3, const mvh_csr_t* up2,
+                    const mvh_csr_t* lap2, const mvh_csr_t* up1, const float* d2, const float* W0, const float* b0,
+                    const float* W1, const float* b1, float* decU0, float* decU1, float* decU2, uint8_t* bits0,
+                    uint8_t* bits1, int B, int CA, int CB, int CC, int K0, int K1, bool out_bf16, bool* handled);
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled, const LdsConvOpts& o = LdsConvOpts());

@@ -295,8 +295,20 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   // the first upsampling takes the dense head's output; the later ones are produced by the previous
   // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
   TRY(check_csr(&d->up[n - 1], "up"));
-  TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
-  for (int i = 0; i < n; ++i) {
+  int first = 0;
+  if (n >= 3) {  // the two coarsest stages with their three upsamplings as ONE launch (cheb_mid.hip)
+    bool mid = false;
+    TRY(check_csr(&d->up[n - 2], "up"));
+    TRY(check_csr(&d->up[n - 3], "up"));
+    TRY(try_mid_dec_fwd((hipStream_t)stream, &d->up[n - 1], &d->lap[n - 1], &d->up[n - 2], &d->lap[n - 2], &d->up[n - 3],
+                        F(p.d2), P[ix.decW(0)], P[ix.decB(0)], P[ix.decW(1)], P[ix.decB(1)], F(p.decU[0]), F(p.decU[1]),
+                        F(p.decU[2]), BITS(p.decBits[0]), BITS(p.decBits[1]), B, p.f[n + 1], p.f[n], p.f[n - 1], d->K[0],
+                        d->K[1], bf, &mid));
+    if (mid) first = 2;
+  }
+  if (first == 0)
+    TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
+  for (int i = first; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
     ConvIO io;
