@@ -54,7 +54,7 @@ struct DebugCfg {
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
   int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
   int no_l0h = 0;          // bf16 storage: keep the unpack-and-v_fma form at the 5k level (no cheb_l0h.hip kernel)
-  int no_mid = 0;          // the small-level sub-networks stay per-layer launches (no cheb_mid.hip kernel)
+  int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
 };
 DebugCfg& dbg();
 
@@ -112,11 +112,6 @@ int l0h_pack_dwords(int K);
 int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, bool dry_run, DwReduceEntry* defer);
-// decoder levels <= 384 vertices as one launch: unpool, conv + ReLU, unpool, conv + ReLU, unpool (cheb_mid.hip)
-int try_mid_dec_fwd(hipStream_t st, const mvh_csr_t* up3, const mvh_csr_t* lap3, const mvh_csr_t* up2,
-                    const mvh_csr_t* lap2, const mvh_csr_t* up1, const float* d2, const float* W0, const float* b0,
-                    const float* W1, const float* b1, float* decU0, float* decU1, float* decU2, uint8_t* bits0,
-                    uint8_t* bits1, int B, int CA, int CB, int CC, int K0, int K1, bool out_bf16, bool* handled);
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled, const LdsConvOpts& o = LdsConvOpts());
@@ -193,11 +188,20 @@ int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int 
                   const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss, void* rec,
                   float* kld, int64_t* correct, int B, int NV, int C, int Z, void* ws, size_t ws_bytes,
                   float* d_recon, float* d_mu, float* d_logvar, float* d_yhat);
-// halves of mvh_vae_latent_bwd: dh + the head pre-activation gradients dpre [B, C + 2Z]; then the weight gradients
+// mvh_vae_latent_fwd with an optional fused dec_lin: d1 = dropout(relu(cat[y, z] Wd^T + bd)) (drop_d: its uniforms, same
+// p), bit-identical to mvh_linear_fwd; *fused tells whether the kernel took it (else the caller launches the GEMM)
+int latent_fwd_impl(hipStream_t st, const float* h, const float* y, const float* drop_u, float p, const float* Wc,
+                    const float* bc, const float* Wm, const float* bm, const float* Wv, const float* bv,
+                    const float* eps, float* y_hat, float* mu, float* logvar, float* z, float* zy, int B, int H, int C,
+                    int Z, const float* Wd, const float* bd, const float* drop_d, float* d1, bool* fused);
+// halves of mvh_vae_latent_bwd: dh + the head pre-activation gradients dpre [B, C + 2Z]; then the weight gradients.
+// With Wd / d1 / g_d1 / g_zy the dX GEMM of dec_lin (mvh_linear_bwd, bit-identical) runs inside the first launch
+// and d_zy is not read (g_zy is written); *fused as above.
 int latent_bwd_heads(hipStream_t st, const float* drop_u, float p, const float* Wc, const float* Wm, const float* Wv,
                      const float* eps, const float* y_hat, const float* logvar, const float* d_yhat,
                      const float* d_mu, const float* d_logvar, const float* d_zy, float* dh, float* dpre, int B,
-                     int H, int C, int Z);
+                     int H, int C, int Z, const float* Wd = nullptr, const float* d1 = nullptr,
+                     const float* g_d1 = nullptr, float* g_zy = nullptr, bool* fused = nullptr);
 int latent_bwd_wgrad(hipStream_t st, const float* h, const float* y, const float* drop_u, float p, const float* dpre,
                      float* dWc, float* dbc, float* dWm, float* dbm, float* dWv, float* dbv, int B, int H, int C,
                      int Z);

@@ -238,13 +238,59 @@ k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const flo
              const float* __restrict__ Wm, const float* __restrict__ bm, const float* __restrict__ Wv,
              const float* __restrict__ bv, const float* __restrict__ eps, float* __restrict__ y_hat,
              float* __restrict__ mu, float* __restrict__ logvar, float* __restrict__ z,
-             float* __restrict__ zy, int H, int C, int Z) {
+             float* __restrict__ zy, int H, int C, int Z, const float* __restrict__ Wd,
+             const float* __restrict__ bd, const float* __restrict__ drop_d, float* __restrict__ d1) {
   extern __shared__ float lds[];
   float* hy = lds;            // [C+H]  = cat[y, h]                      (cheb_VAE.py:209)
   float* hd = lds + C + H;    // [H]    = classifier's dropout(h)        (cheb_VAE.py:255)
   float* outs = hd + H;       // [C+2Z] logits | mu | logvar
+  float* zyl = outs + C + 2 * Z;  // [C+Z] = cat[y, z] for the fused dec_lin
   const int b = blockIdx.x;
   const float scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+  // Fused dec_lin (cheb_VAE.py:277, Wd != NULL; the launcher checks C + Z < 32 and H <= 512): d1 = dropout(relu(
+  // cat[y, z] Wd^T + bd)) for this mesh, in the arithmetic of k_gemm16 (the module path's mvh_linear_fwd) to the
+  // last bit -- same matrix instructions on the same lanes, its per-wave partial sums added in its order -- so one
+  // launch less changes no result.  The weight tiles do not depend on z: they are fetched now, under the heads.
+  const int Kd = C + Z;
+  float wdr[2][2][4];   // [tile][full 16-chunk | K tail][t]
+  float bdr[2] = {0.f, 0.f}, udr[2] = {1.f, 1.f};   // bias and dropout uniform of the lane's output
+  if (Wd) {
+    const int lane_ = threadIdx.x & 63, i_ = lane_ & 15, kq_ = lane_ >> 4, wave_ = threadIdx.x >> 6;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int n0 = (wave_ + 16 * tl) * 16;
+      const float* wr = Wd + (long long)min(n0 + i_, H - 1) * Kd;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 4 * kq_ + t, kt = (Kd & ~15) + k;
+        wdr[tl][0][t] = (n0 < H && k < (Kd & ~15)) ? wr[k] : 0.f;
+        wdr[tl][1][t] = (n0 < H && kt < Kd) ? wr[kt] : 0.f;
+      }
+      const bool mine = kq_ == 0 && n0 + i_ < H;
+      bdr[tl] = mine ? bd[n0 + i_] : 0.f;
+      udr[tl] = (mine && drop_d && p > 0.f) ? drop_d[(long long)b * H + n0 + i_] : 1.f;
+    }
+  }
+  // The head weights do not depend on h either: when a lane's share of the (at most three) outputs its wave owns
+  // fits in registers, every global load of the kernel is issued here, in front of the first barrier
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, nw = blockDim.x / 64;
+  constexpr int kHR = 3, kHC = 9;
+  const bool fast = (C + H <= 64 * kHC) && (C + 2 * Z <= kHR * nw);
+  float wq[kHR][kHC], bq[kHR];
+  if (fast) {
+#pragma unroll
+    for (int r = 0; r < kHR; ++r) {
+      const int o = wave + r * nw;
+      const bool live = o < C + 2 * Z, cls = o < C;
+      const int zz = cls ? 0 : (o - C) % Z;
+      const bool is_mu = (o - C) < Z;
+      const float* w = cls ? Wc + (long long)o * H : (is_mu ? Wm : Wv) + (long long)zz * (C + H);
+      const int len = cls ? H : C + H;
+      bq[r] = live ? (cls ? bc[o] : (is_mu ? bm[zz] : bv[zz])) : 0.f;
+#pragma unroll
+      for (int c = 0; c < kHC; ++c) wq[r][c] = (live && lane + 64 * c < len) ? w[lane + 64 * c] : 0.f;
+    }
+  }
   for (int j = threadIdx.x; j < H; j += blockDim.x) {
     const float v = h[(long long)b * H + j];
     hy[C + j] = v;
@@ -252,39 +298,40 @@ k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const flo
   }
   for (int j = threadIdx.x; j < C; j += blockDim.x) hy[j] = y[(long long)b * C + j];
   __syncthreads();
-  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, nw = blockDim.x / 64;
-  for (int o = wave; o < C + 2 * Z; o += nw) {
-    float s = 0.f;
-    if (o < C) {
-      const float* w = Wc + (long long)o * H;
+  if (fast) {
+#pragma unroll
+    for (int r = 0; r < kHR; ++r) {
+      const int o = wave + r * nw;
+      if (o >= C + 2 * Z) break;  // wave-uniform
+      const float* x = (o < C) ? hd : hy;
+      const int len = (o < C) ? H : C + H;
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < kHC; ++c) s = fmaf(lane + 64 * c < len ? x[lane + 64 * c] : 0.f, wq[r][c], s);
+      s = wave_sum(s);
+      if (lane == 0) outs[o] = s + bq[r];
+    }
+  } else {
+    for (int o = wave; o < C + 2 * Z; o += nw) {
+      float s = 0.f;
+      const bool cls = o < C;
+      const int zz = cls ? 0 : (o - C) % Z;
+      const bool is_mu = (o - C) < Z;
+      const float* w = cls ? Wc + (long long)o * H : (is_mu ? Wm : Wv) + (long long)zz * (C + H);
+      const float* x = cls ? hd : hy;
+      const int len = cls ? H : C + H;
       float s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the row's loads are in flight together
       int j = lane;
-      for (; j + 192 < H; j += 256) {
-        s = fmaf(hd[j], w[j], s);
-        s1 = fmaf(hd[j + 64], w[j + 64], s1);
-        s2 = fmaf(hd[j + 128], w[j + 128], s2);
-        s3 = fmaf(hd[j + 192], w[j + 192], s3);
+      for (; j + 192 < len; j += 256) {
+        s = fmaf(x[j], w[j], s);
+        s1 = fmaf(x[j + 64], w[j + 64], s1);
+        s2 = fmaf(x[j + 128], w[j + 128], s2);
+        s3 = fmaf(x[j + 192], w[j + 192], s3);
       }
-      for (; j < H; j += 64) s = fmaf(hd[j], w[j], s);
+      for (; j < len; j += 64) s = fmaf(x[j], w[j], s);
       s = (s + s1) + (s2 + s3);
       s = wave_sum(s);
-      if (lane == 0) outs[o] = s + bc[o];
-    } else {
-      const int zz = (o - C) % Z;
-      const bool is_mu = (o - C) < Z;
-      const float* w = (is_mu ? Wm : Wv) + (long long)zz * (C + H);
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int j = lane;
-      for (; j + 192 < C + H; j += 256) {
-        s = fmaf(hy[j], w[j], s);
-        s1 = fmaf(hy[j + 64], w[j + 64], s1);
-        s2 = fmaf(hy[j + 128], w[j + 128], s2);
-        s3 = fmaf(hy[j + 192], w[j + 192], s3);
-      }
-      for (; j < C + H; j += 64) s = fmaf(hy[j], w[j], s);
-      s = (s + s1) + (s2 + s3);
-      s = wave_sum(s);
-      if (lane == 0) outs[o] = s + (is_mu ? bm[zz] : bv[zz]);
+      if (lane == 0) outs[o] = s + (cls ? bc[o] : (is_mu ? bm[zz] : bv[zz]));
     }
   }
   __syncthreads();
@@ -303,37 +350,182 @@ k_latent_fwd(const float* __restrict__ h, const float* __restrict__ y, const flo
     logvar[(long long)b * Z + t] = lv;
     z[(long long)b * Z + t] = zz;
     zy[(long long)b * (C + Z) + C + t] = zz;
+    zyl[C + t] = zz;
   }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) zy[(long long)b * (C + Z) + c] = hy[c];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    zy[(long long)b * (C + Z) + c] = hy[c];
+    zyl[c] = hy[c];
+  }
+  if (!Wd) return;
+  __syncthreads();
+  {
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, wave = threadIdx.x >> 6;
+    const int Kfull = Kd & ~15;
+    const float keep = (drop_d && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int n0 = (wave + 16 * tl) * 16;
+      if (n0 >= H) continue;  // wave-uniform
+      // k_gemm16 with K = Kd <= 32 runs NW = cdiv(Kd, 16) waves: wave 0 the full chunk [0, 16), the K tail on wave
+      // (Kfull / 16) % NW, and wave 0 then adds the others' accumulators in wave order
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if (Kfull >= 16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(zyl[4 * kq + t], wdr[tl][0][t], acc0, 0, 0, 0);
+      }
+      if (Kfull < Kd) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = Kfull + 4 * kq + t;
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k < Kd ? zyl[k] : 0.f, wdr[tl][1][t], acc1, 0, 0, 0);
+        }
+      }
+      // NW == 1 (Kd < 16): the tail lands on wave 0 itself, i.e. on the same accumulator; NW == 2: a separate one
+      float v = (Kfull >= 16) ? ((Kfull < Kd) ? acc0[0] + acc1[0] : acc0[0]) : acc1[0];
+      const int n = n0 + i;
+      if (kq == 0 && n < H) {
+        v += bdr[tl];
+        v = fmaxf(v, 0.f);
+        if (drop_d && p > 0.f) v = (udr[tl] >= p) ? v * keep : 0.f;
+        d1[(long long)b * H + n] = v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ latent head, backward
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_latent_bwd(const float* __restrict__ drop_u, float p, const float* __restrict__ Wc,
              const float* __restrict__ Wm, const float* __restrict__ Wv, const float* __restrict__ eps,
              const float* __restrict__ y_hat, const float* __restrict__ logvar,
              const float* __restrict__ d_yhat, const float* __restrict__ d_mu,
              const float* __restrict__ d_logvar, const float* __restrict__ d_zy, float* __restrict__ dh,
-             float* __restrict__ dpre, int H, int C, int Z) {
+             float* __restrict__ dpre, int H, int C, int Z, const float* __restrict__ Wd,
+             const float* __restrict__ d1, const float* __restrict__ g_d1, float* __restrict__ g_zy) {
   extern __shared__ float lds[];
   float* g = lds;  // [C+2Z]: dlogit | dmu | dlogvar
   const int b = blockIdx.x;
+  float* part = g + C + 2 * Z;      // [2 tiles][8 waves][16]
+  float* dzl = part + 2 * 8 * 16;   // [C+Z]
+  float* yl = dzl + C + Z;          // [2C]: y_hat | d_yhat
+  // ---- the head inputs of thread t < Z / c < C do not depend on g_zy: their loads are issued first
+  const int no = C + 2 * Z;
+  float p_mu = 0.f, p_lv = 0.f, p_eps = 0.f, p_logvar = 0.f, p_y = 0.f, p_dy = 0.f;
+  if ((int)threadIdx.x < Z) {
+    p_mu = d_mu[(long long)b * Z + threadIdx.x];
+    p_lv = d_logvar[(long long)b * Z + threadIdx.x];
+    if (eps) {
+      p_eps = eps[(long long)b * Z + threadIdx.x];
+      p_logvar = logvar[(long long)b * Z + threadIdx.x];
+    }
+  }
+  if ((int)threadIdx.x < C) {
+    p_y = y_hat[(long long)b * C + threadIdx.x];
+    p_dy = d_yhat[(long long)b * C + threadIdx.x];
+  }
+  // Fused dX of dec_lin (Wd != NULL; launcher: C + Z <= 32, 512 threads): g_zy[b] = (g_d1[b] masked by d1[b] > 0 and
+  // rescaled) Wd, i.e. mvh_linear_bwd's dX GEMM for this mesh in the arithmetic of k_gemm16 to the last bit: wave w
+  // plays that kernel's wave w for both 16-column tiles (its interleaved 16-chunks of K = H and, on one wave, the K
+  // tail, same lanes, same instruction order; the A operand is shared by the tiles); the accumulators are then added
+  // in wave order.  (8 waves and ~70 VGPRs on purpose: this launch runs beside the chip-filling weight-gradient
+  // kernels of the side lane and must fit into what they leave free.)
+  int NW = (H + 15) / 16;
+  NW = NW < 1 ? 1 : (NW > kGemmWaves ? kGemmWaves : NW);
+  if (Wd) {
+    const int Kd = C + Z;
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const bool two = Kd > 16;
+    if (w < NW) {  // wave-uniform
+      const int Kfull = H & ~15, kStep = 16 * NW;
+      const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+      const float* __restrict__ ap = g_d1 + (long long)b * H;
+      const float* __restrict__ mp = d1 + (long long)b * H;
+      const float* __restrict__ bp0 = Wd + min(i, Kd - 1);
+      const float* __restrict__ bp1 = Wd + min(16 + i, Kd - 1);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      auto load_chunk = [&](int k, float (&a)[4], float (&b0)[4], float (&b1)[4]) {  // k .. k + 3 all < H
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = ap[k + t], mv = mp[k + t];
+          a[t] = mv > 0.f ? av * sc : 0.f;
+          b0[t] = bp0[(long long)(k + t) * Kd];
+          b1[t] = two ? bp1[(long long)(k + t) * Kd] : 0.f;
+        }
+      };
+      auto mma = [&](const float (&a)[4], const float (&b0)[4], const float (&b1)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b0[t], acc0, 0, 0, 0);
+        if (two) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b1[t], acc1, 0, 0, 0);
+        }
+      };
+      int k0 = 16 * w;
+      for (; k0 + 3 * kStep < Kfull; k0 += 4 * kStep) {  // four chunks of loads in flight
+        float a[4][4], b0[4][4], b1[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load_chunk(k0 + c * kStep + 4 * kq, a[c], b0[c], b1[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma(a[c], b0[c], b1[c]);
+      }
+      for (; k0 < Kfull; k0 += kStep) {
+        float a[4], b0[4], b1[4];
+        load_chunk(k0 + 4 * kq, a, b0, b1);
+        mma(a, b0, b1);
+      }
+      if (Kfull < H && w == ((Kfull >> 4) % NW)) {  // K tail
+        float a[4], b0[4], b1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = Kfull + 4 * kq + t;
+          a[t] = b0[t] = b1[t] = 0.f;
+          if (k < H) {
+            a[t] = mp[k] > 0.f ? ap[k] * sc : 0.f;
+            b0[t] = bp0[(long long)k * Kd];
+            if (two) b1[t] = bp1[(long long)k * Kd];
+          }
+        }
+        mma(a, b0, b1);
+      }
+      if (kq == 0) {   // output row 0 (every row of the tile is this mesh)
+        part[w * 16 + i] = acc0[0];
+        part[(kGemmWaves + w) * 16 + i] = acc1[0];
+      }
+    }
+  }
+  if ((int)threadIdx.x < C) {
+    yl[threadIdx.x] = p_y;
+    yl[C + threadIdx.x] = p_dy;
+  }
+  __syncthreads();
+  if (Wd) {
+    const int Kd = C + Z;
+    for (int n = threadIdx.x; n < Kd; n += blockDim.x) {
+      const int tile = n >> 4, i2 = n & 15;
+      float tot = part[(tile * kGemmWaves) * 16 + i2];
+      for (int w = 1; w < NW; ++w) tot += part[(tile * kGemmWaves + w) * 16 + i2];
+      dzl[n] = tot;
+      g_zy[(long long)b * Kd + n] = tot;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(d_yhat[(long long)b * C + c], y_hat[(long long)b * C + c], s);
-    for (int c = 0; c < C; ++c)
-      g[c] = y_hat[(long long)b * C + c] * (d_yhat[(long long)b * C + c] - s);
+    for (int c = 0; c < C; ++c) s = fmaf(yl[C + c], yl[c], s);
+    for (int c = 0; c < C; ++c) g[c] = yl[c] * (yl[C + c] - s);
   }
-  for (int t = threadIdx.x; t < Z; t += blockDim.x) {
-    const float dz = d_zy[(long long)b * (C + Z) + C + t];
-    float dm = d_mu[(long long)b * Z + t] + dz;
-    float dl = d_logvar[(long long)b * Z + t];
-    if (eps) dl = fmaf(dz * eps[(long long)b * Z + t], 0.5f * expf(0.5f * logvar[(long long)b * Z + t]), dl);
+  if ((int)threadIdx.x < Z) {
+    const int t = threadIdx.x;
+    const float dz = Wd ? dzl[C + t] : d_zy[(long long)b * (C + Z) + C + t];
+    float dm = p_mu + dz;
+    float dl = p_lv;
+    if (eps) dl = fmaf(dz * p_eps, 0.5f * expf(0.5f * p_logvar), dl);
     g[C + t] = dm;
     g[C + Z + t] = dl;
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < C + 2 * Z; o += blockDim.x) dpre[(long long)b * (C + 2 * Z) + o] = g[o];
+  for (int o = threadIdx.x; o < no; o += blockDim.x) dpre[(long long)b * no + o] = g[o];
   const float scale = (drop_u && p > 0.f) ? 1.f / (1.f - p) : 1.f;
   for (int j = threadIdx.x; j < H; j += blockDim.x) {
     float a = 0.f;
@@ -432,21 +624,32 @@ extern "C" int mvh_linear_bwd(mvh_stream_t stream, const float* x, const float* 
   return launch_gemm_ex(st, dy, 1, out_f, x, in_f, 1, dW, out_f, in_f, B, nullptr, 0, nullptr, 0.f, mask, scale, db);
 }
 
+// latent heads (+ optionally dec_lin, see k_latent_fwd) of the whole batch in one launch
+int mvh::latent_fwd_impl(hipStream_t st, const float* h, const float* y, const float* drop_u, float p, const float* Wc,
+                         const float* bc, const float* Wm, const float* bm, const float* Wv, const float* bv,
+                         const float* eps, float* y_hat, float* mu, float* logvar, float* z, float* zy, int B, int H,
+                         int C, int Z, const float* Wd, const float* bd, const float* drop_d, float* d1, bool* fused) {
+  MVH_REQUIRE(h && y && Wc && bc && Wm && bm && Wv && bv && y_hat && mu && logvar && z && zy, "latent_fwd: null tensor");
+  MVH_REQUIRE(H > 0 && C > 0 && Z > 0 && B >= 0, "latent_fwd: bad sizes");
+  MVH_REQUIRE(p >= 0.f && p < 1.f, "latent_fwd: dropout p out of range");
+  const bool fuse = Wd && bd && d1 && C + Z < 32 && H <= 512 && !dbg().force_generic && !dbg().no_head_fuse;
+  if (fused) *fused = fuse;
+  if (B == 0) return MVH_OK;
+  const size_t lds = (size_t)(C + H + H + C + 2 * Z + C + Z) * sizeof(float);
+  MVH_REQUIRE(lds <= 64 * 1024, "latent_fwd: hidden size %d too large", H);
+  hipLaunchKernelGGL(k_latent_fwd, dim3(B), dim3(1024), lds, st, h, y, drop_u, p, Wc, bc, Wm, bm, Wv, bv, eps, y_hat, mu,
+                     logvar, z, zy, H, C, Z, fuse ? Wd : nullptr, bd, drop_d, d1);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
 extern "C" int mvh_vae_latent_fwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
                                   float p, const float* Wc, const float* bc, const float* Wm,
                                   const float* bm, const float* Wv, const float* bv, const float* eps,
                                   float* y_hat, float* mu, float* logvar, float* z, float* zy, int32_t B,
                                   int32_t H, int32_t C, int32_t Z) {
-  MVH_REQUIRE(h && y && Wc && bc && Wm && bm && Wv && bv && y_hat && mu && logvar && z && zy, "latent_fwd: null tensor");
-  MVH_REQUIRE(H > 0 && C > 0 && Z > 0 && B >= 0, "latent_fwd: bad sizes");
-  MVH_REQUIRE(p >= 0.f && p < 1.f, "latent_fwd: dropout p out of range");
-  if (B == 0) return MVH_OK;
-  const size_t lds = (size_t)(C + H + H + C + 2 * Z) * sizeof(float);
-  MVH_REQUIRE(lds <= 64 * 1024, "latent_fwd: hidden size %d too large", H);
-  hipLaunchKernelGGL(k_latent_fwd, dim3(B), dim3(1024), lds, (hipStream_t)stream, h, y, drop_u, p, Wc, bc, Wm,
-                     bm, Wv, bv, eps, y_hat, mu, logvar, z, zy, H, C, Z);
-  MVH_LAUNCH_CHECK();
-  return MVH_OK;
+  return latent_fwd_impl((hipStream_t)stream, h, y, drop_u, p, Wc, bc, Wm, bm, Wv, bv, eps, y_hat, mu, logvar, z, zy, B, H,
+                         C, Z, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int mvh_vae_latent_bwd(mvh_stream_t stream, const float* h, const float* y, const float* drop_u,
@@ -469,11 +672,17 @@ extern "C" int mvh_vae_latent_bwd(mvh_stream_t stream, const float* h, const flo
 int mvh::latent_bwd_heads(hipStream_t st, const float* drop_u, float p, const float* Wc, const float* Wm,
                           const float* Wv, const float* eps, const float* y_hat, const float* logvar,
                           const float* d_yhat, const float* d_mu, const float* d_logvar, const float* d_zy,
-                          float* dh, float* dpre, int B, int H, int C, int Z) {
+                          float* dh, float* dpre, int B, int H, int C, int Z, const float* Wd, const float* d1,
+                          const float* g_d1, float* g_zy, bool* fused) {
   const int no = C + 2 * Z;
+  // optional: the dX GEMM of dec_lin (g_d1 -> g_zy, which then is an output) inside the same launch
+  const bool fuse = Wd && d1 && g_d1 && g_zy && C + Z <= 32 && !dbg().force_generic && !dbg().no_head_fuse;
+  if (fused) *fused = fuse;
+  MVH_REQUIRE(fuse || d_zy, "latent_bwd: null tensor");
   if (B > 0) {
-    hipLaunchKernelGGL(k_latent_bwd, dim3(B), dim3(256), (size_t)no * sizeof(float), st, drop_u, p, Wc, Wm, Wv,
-                       eps, y_hat, logvar, d_yhat, d_mu, d_logvar, d_zy, dh, dpre, H, C, Z);
+    const size_t lds = (size_t)(no + 2 * kGemmWaves * 16 + C + Z + 2 * C) * sizeof(float);
+    hipLaunchKernelGGL(k_latent_bwd, dim3(B), dim3(fuse ? 512 : 256), lds, st, drop_u, p, Wc, Wm, Wv, eps, y_hat, logvar,
+                       d_yhat, d_mu, d_logvar, d_zy, dh, dpre, H, C, Z, fuse ? Wd : nullptr, d1, g_d1, g_zy);
     MVH_LAUNCH_CHECK();
   }
   return MVH_OK;

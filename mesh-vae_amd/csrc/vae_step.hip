@@ -284,31 +284,24 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], h_out ? h_out : F(p.h), B, p.flat, p.H, MVH_ACT_RELU,
                        u_enc, pd));
   // ---- classifier + latent heads + reparameterisation (cheb_VAE.py:203-226)
-  if (phases & kPhHead)
-    TRY(mvh_vae_latent_fwd(stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
-                           P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z));
+  bool d1_done = false;   // dec_lin rides in the latent-head launch when the step runs both (one launch less)
+  if (phases & kPhHead) {
+    const bool with_dec = (phases & kPhDec) && !zy_in;
+    TRY(latent_fwd_impl((hipStream_t)stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
+                        P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z,
+                        with_dec ? P[ix.decLW()] : nullptr, P[ix.decLB()], u_d1, F(p.d1), &d1_done));
+  }
   if (!(phases & kPhDec)) return MVH_OK;
   // ---- decoder (cheb_VAE.py:275-292)
-  TRY(mvh_linear_fwd(stream, zy_in ? zy_in : F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H,
-                     MVH_ACT_RELU, u_d1, pd));
+  if (!d1_done)
+    TRY(mvh_linear_fwd(stream, zy_in ? zy_in : F(p.zy), P[ix.decLW()], P[ix.decLB()], F(p.d1), B, p.C + p.Z, p.H,
+                       MVH_ACT_RELU, u_d1, pd));
   TRY(mvh_linear_fwd(stream, F(p.d1), P[ix.dl2W()], P[ix.dl2B()], F(p.d2), B, p.H, p.flat, MVH_ACT_RELU, u_d2, pd));
   // the first upsampling takes the dense head's output; the later ones are produced by the previous
   // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
   TRY(check_csr(&d->up[n - 1], "up"));
-  int first = 0;
-  if (n >= 3) {  // the two coarsest stages with their three upsamplings as ONE launch (cheb_mid.hip)
-    bool mid = false;
-    TRY(check_csr(&d->up[n - 2], "up"));
-    TRY(check_csr(&d->up[n - 3], "up"));
-    TRY(try_mid_dec_fwd((hipStream_t)stream, &d->up[n - 1], &d->lap[n - 1], &d->up[n - 2], &d->lap[n - 2], &d->up[n - 3],
-                        F(p.d2), P[ix.decW(0)], P[ix.decB(0)], P[ix.decW(1)], P[ix.decB(1)], F(p.decU[0]), F(p.decU[1]),
-                        F(p.decU[2]), BITS(p.decBits[0]), BITS(p.decBits[1]), B, p.f[n + 1], p.f[n], p.f[n - 1], d->K[0],
-                        d->K[1], bf, &mid));
-    if (mid) first = 2;
-  }
-  if (first == 0)
-    TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
-  for (int i = first; i < n; ++i) {
+  TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
+  for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
     ConvIO io;
@@ -527,6 +520,16 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     io.x = io.dout = io.dx = bf;
     io.dx_pooled = bf && i > 0;   // (stage 0 hands its pooled gradient to the fp32 dense head)
     if (i == n - 1 && p.pk_h_b != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_b));
+    // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
+    float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
+    auto dx_this = [&]() -> int {
+      return conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
+                          F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]), io,
+                          nullptr, &d->up_t[lvl], dst);
+    };
+    // (MEASURED, not kept: at the level-0 stage launching this dX BEFORE forking the dW, so that the chip-filling dW
+    //  waits for it, alone or with the dW launch cut into two 128-workgroup halves that leave half the chip to the
+    //  main chain: 576 / 594 us per step against 573 -- the weight-gradient lane then finishes last)
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
                      p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));
@@ -545,20 +548,23 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       }
       side->tstack_pending = false;
     }
-    // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
-    float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
-    TRY(conv_dx_main(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
-                     F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]), io,
-                     nullptr, &d->up_t[lvl], dst));
+    TRY(dx_this());
   }
   // ---- dense decoder head, latent heads, dense encoder head: the dX chain stays on the main stream,
   //      every weight gradient (4 GEMMs + the head gradients) goes to the dense lane after ONE fork
   TRY(mvh_linear_bwd(stream, F(p.d1), P[ix.dl2W()], F(p.d2), F(p.g_d2), F(p.g_d1), nullptr, nullptr, B, p.H, p.flat,
                      MVH_ACT_RELU, pd, sm, p.scratch_bytes));
-  TRY(mvh_linear_bwd(stream, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), F(p.g_zy), nullptr, nullptr, B, p.C + p.Z,
-                     p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
-  TRY(latent_bwd_heads(main, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar, F(p.d_yhat),
-                       F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), F(p.d_heads), B, p.H, p.C, p.Z));
+  {  // dec_lin's dX (g_d1 -> g_zy) inside the latent-head launch when eligible, else as its own GEMM first
+    bool probe = false;
+    const bool try_fuse = p.C + p.Z <= 32 && !dbg().force_generic && !dbg().no_head_fuse;
+    if (!try_fuse)
+      TRY(mvh_linear_bwd(stream, F(p.zy), P[ix.decLW()], F(p.d1), F(p.g_d1), F(p.g_zy), nullptr, nullptr, B, p.C + p.Z,
+                         p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));
+    TRY(latent_bwd_heads(main, u_cls, pd, P[ix.clsW()], P[ix.zmW()], P[ix.zvW()], eps, y_hat, logvar, F(p.d_yhat),
+                         F(p.d_mu), F(p.d_lv), F(p.g_zy), F(p.g_h), F(p.d_heads), B, p.H, p.C, p.Z,
+                         try_fuse ? P[ix.decLW()] : nullptr, F(p.d1), F(p.g_d1), F(p.g_zy), &probe));
+    MVH_REQUIRE(probe == try_fuse, "vae_backward: latent head fusion mismatch");
+  }
   TRY(flush_dw(true));  // one fork: queued conv dW -> side lane, dense weight gradients -> dense lane
   TRY(mvh_linear_bwd(stream, F(p.encP[n - 1]), P[ix.encLW()], F(p.h), F(p.g_h), F(p.g_encP[n - 1]), nullptr, nullptr,
                      B, p.flat, p.H, MVH_ACT_RELU, pd, sm, p.scratch_bytes));

@@ -326,6 +326,44 @@ def test_native_step_unusual_configs_match_module_path(cfg_over, B):
             assert err < 1e-4, (k, err)
 
 
+@pytest.mark.parametrize("which,B,dropout", [("tiny", 5, 0.2), ("5k", 3, 0.2), ("5k", 2, 0.0)])
+def test_fused_head_kernels_are_bitwise_the_separate_launches(which, B, dropout):
+    """dec_lin (cheb_VAE.py:277) rides inside the latent-head launches of the native step, forward and dX (dense.hip:
+    k_latent_fwd / k_latent_bwd evaluate it with the matrix instructions, lanes and summation order of k_gemm16).
+    Against the same step with the debug switch no_head_fuse (dec_lin as its own mvh_linear_fwd / mvh_linear_bwd GEMM)
+    every output and every gradient must be IDENTICAL, with and without dropout, for H = 64 (4 K-waves) and H = 512 (8)."""
+    from conftest import CFG_5K
+    from meshvae_hip import debug_switch
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    cfg, topo, N = (TINY_CFG, "topology_tiny.npz", 162) if which == "tiny" else (CFG_5K, "topology_5k.npz", 4998)
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", topo), dev)
+    x = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(21)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=torch.Generator().manual_seed(22)).to(dev)
+    res = []
+    for no_fuse in (1, 0):
+        torch.manual_seed(5)
+        net = cheb_VAE(3, dict(cfg, dropout=dropout), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
+        nat = NativeStep(net, B)
+        drop_u = None
+        if dropout > 0:                                          # the dropout uniforms of this step [B, 3 H + flat]
+            drop_u = torch.rand(B, nat.u_cols, generator=torch.Generator().manual_seed(77)).to(dev)
+        with debug_switch("no_head_fuse", no_fuse):
+            loss, corr, recon, (kld, rec, z), yh = nat.forward_backward(x, x, y, eps=eps, drop_u=drop_u)
+            torch.cuda.synchronize()
+        res.append((loss.clone(), recon.clone(), z.clone(), yh.clone(),
+                    {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    a, b = res
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    assert sorted(a[4]) == sorted(b[4])
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+
+
 def test_dense_gradients_are_final_at_the_library_event():
     """The overlapped all-reduce (engine.TrainStep._all_reduce_overlapped) reads the dense-layer gradients on
     another stream as soon as the event behind mvh_vae_wait_dense_grads fires, while the encoder half of the
