@@ -90,7 +90,7 @@ int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
 /* Debug / A-B switches (no reference counterpart).  They live in ONE struct that is filled when the
  * library is loaded from MESHVAE_DEBUG="key=value,..." and is never re-read from the environment;
  * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch,
- * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse.  mvh_debug_set changes one switch in-process (the tests
+ * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse, no_big.  mvh_debug_set changes one switch in-process (the tests
  * run both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
 int mvh_debug_set(const char* key, int32_t value);
 int32_t mvh_debug_get(const char* key);
@@ -119,7 +119,9 @@ int mvh_pool_bwd(mvh_stream_t stream, const mvh_csr_t* pool_t, const float* dy, 
  * with the norm of nn/conv.py:541-555 as values; lap->n_rows == lap->n_cols == N, and
  * rows without edges are simply empty (the final-layer quirk, cheb_VAE.py:288).
  * W is [K,Cin,Cout]; bias [Cout] or NULL.  `ws` must hold mvh_cheb_conv_ws_bytes().
- * If `tx_saved` is non-NULL it receives T_1..T_{K-1} ([K-1,B,N,Cin]) for the backward. */
+ * If `tx_saved` is non-NULL it receives T_1..T_{K-1} for the backward: (K-1)*B*N*Cin floats in a layout private to
+ * the library ([K-1,B,N,Cin] rows, or pair-major planes [K-1,B,Cin/2,N,2] where csrc/cheb_big.hip builds the
+ * stack); hand the buffer to mvh_cheb_conv_bwd unchanged. */
 size_t mvh_cheb_conv_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K);
 int mvh_cheb_conv_fwd(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, const float* W,
                       const float* bias, float* out, float* tx_saved,

@@ -36,8 +36,8 @@ static const DebugKey kDebugKeys[] = {
     {"fork_batch", &DebugCfg::fork_batch},       {"no_gstack_mfma", &DebugCfg::no_gstack_mfma},
     {"no_dw_mfma", &DebugCfg::no_dw_mfma},       {"no_xcd_remap", &DebugCfg::no_xcd_remap},
     {"no_prefetch", &DebugCfg::no_prefetch},     {"no_l0h", &DebugCfg::no_l0h},
-    {"no_head_fuse", &DebugCfg::no_head_fuse},
-    {"no_head_fuse", &DebugCfg::no_head_fuse},
+    {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
+    {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

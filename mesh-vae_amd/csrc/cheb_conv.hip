@@ -15,13 +15,16 @@
 
 namespace mvh {
 
+static bool dw_is_mfma(long long rows, int Cout);
+
 // ------------------------------------------------------------------ forward contraction
 template <int COUT_T, bool FULL, bool VIN>
 __global__ void __launch_bounds__(256)
 k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ W,
                 const float* __restrict__ bias, float* __restrict__ out, long long rows, int Cin,
-                int Cout, int K, int act, int x_bf16) {
+                int Cout, int K, int act, int x_bf16, int pmN) {
   // x_bf16: x is stored as bf16 (K == 1 only: the W_eff pass of the split path; the launcher checks)
+  // pmN > 0: the stack planes tx are pair-major [B][8][pmN][2] (cheb_big.hip; 16 -> 16 only, the launcher checks)
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float acc[COUT_T];
@@ -35,11 +38,25 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[j] = s0[j];
       }
+      long long pm_off = 0;   // (float2 units) of (mesh, pair 0, vertex) inside a pair-major plane
+      if (pmN) {
+        const int rr = (int)r, b = rr / pmN;
+        pm_off = (long long)b * 8 * pmN + (rr - b * pmN);
+      }
       for (int k = 0; k < K; ++k) {
         const int kn = min(k + 1, K - 1);  // (the last trip re-reads its own plane: no branch around the loads)
-        const float4* sn = reinterpret_cast<const float4*>((kn == 0 ? x : tx + (long long)(kn - 1) * rows * 16) + r * 16);
+        if (pmN && kn > 0) {
+          const float2* sp = reinterpret_cast<const float2*>(tx + (long long)(kn - 1) * rows * 16) + pm_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nxt[j] = sn[j];
+          for (int j = 0; j < 4; ++j) {
+            const float2 lo = sp[(long long)(2 * j) * pmN], hi = sp[(long long)(2 * j + 1) * pmN];
+            nxt[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+          }
+        } else {
+          const float4* sn = reinterpret_cast<const float4*>((kn == 0 ? x : tx + (long long)(kn - 1) * rows * 16) + r * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nxt[j] = sn[j];
+        }
         const float* Wk = W + (long long)k * 16 * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -100,15 +117,17 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
 
 static int launch_contract(hipStream_t st, const float* x, const float* tx, const float* W,
                            const float* bias, float* out, long long rows, int Cin, int Cout, int K,
-                           int act, bool x_bf16 = false) {
+                           int act, bool x_bf16 = false, int pmN = 0) {
   const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
+  // pmN > 0: pair-major stack planes -- only the 16 -> 16 fast path of the kernel reads them
+  if (pmN && !(vin && Cin == 16 && Cout == 16)) return fail(MVH_ERR_INVALID, "cheb_conv: pair-major stack outside the 16 -> 16 contraction");
   if (x_bf16 && (!vin || K != 1 || (Cin == 16 && Cout == 16)))
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 rows reach the contraction only through the K = 1 split pass");
   const int xb = x_bf16 ? 1 : 0;
   const int grid = cdiv(rows, 256);
 #define MVH_C(CT, FULL, VIN)                                                                    \
   hipLaunchKernelGGL((k_cheb_contract<CT, FULL, VIN>), dim3(grid), dim3(256), 0, st, x, tx, W,  \
-                     bias, out, rows, Cin, Cout, K, act, xb)
+                     bias, out, rows, Cin, Cout, K, act, xb, pmN)
 #define MVH_CV(CT, FULL) \
   do { if (vin) MVH_C(CT, FULL, true); else MVH_C(CT, FULL, false); } while (0)
   if (Cout == 3) MVH_CV(3, true);
@@ -210,7 +229,10 @@ typedef float f32x4_g __attribute__((ext_vector_type(4)));
 template <int KMAX, bool RELU>
 __global__ void __launch_bounds__(256)
 k_gstack_mfma16(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ W,
-                float* __restrict__ G, float* __restrict__ g0, long long rows, int K, long long blocks_per_wave) {
+                float* __restrict__ G, float* __restrict__ g0, long long rows, int K, long long blocks_per_wave,
+                int pmN) {
+  // pmN > 0: the planes leave pair-major, [B][8][pmN][2] (what cheb_big.hip's Clenshaw kernel streams): lane (m, q)
+  // holds the channels 4 q .. 4 q + 3 of its row = the pairs 2 q and 2 q + 1, 16 lanes write 128 contiguous bytes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
   float4 wa[KMAX];
@@ -237,15 +259,30 @@ k_gstack_mfma16(const float* __restrict__ dout, const float* __restrict__ out, c
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].z, d.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].w, d.w, acc, 0, 0, 0);
         float* dst = (k == 0 ? g0 : G + (long long)k * rows * 16);
-        if (row_raw < rows)
-          *reinterpret_cast<float4*>(dst + row_raw * 16 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (row_raw < rows) {
+          if (pmN) {
+            const int rr = (int)row_raw, b = rr / pmN, v = rr - b * pmN;
+            float2* pp = reinterpret_cast<float2*>(dst) + ((long long)(b * 8 + 2 * q) * pmN + v);
+            pp[0] = make_float2(acc[0], acc[1]);
+            pp[pmN] = make_float2(acc[2], acc[3]);
+          } else {
+            *reinterpret_cast<float4*>(dst + row_raw * 16 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          }
+        }
       }
     }
   }
 }
 
+static bool gstack_is_mfma(const float* dout, const float* out, const float* W, const float* G, const float* g0,
+                           long long rows, int Cin, int Cout, int K) {
+  return Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !dbg().no_gstack_mfma &&
+         (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)W | (uintptr_t)G | (uintptr_t)g0) & 15) == 0;
+}
+
+// pmN > 0 (only where gstack_is_mfma holds): the planes are written pair-major for cheb_big.hip
 static int launch_gstack(hipStream_t st, const float* dout, const float* out, const float* W, float* G,
-                         float* g0, long long rows, int Cin, int Cout, int K, int act, bool g_bf16 = false) {
+                         float* g0, long long rows, int Cin, int Cout, int K, int act, bool g_bf16 = false, int pmN = 0) {
   if (K == 1 && (Cin & 3) == 0 && ((uintptr_t)g0 & 15) == 0 && (Cout == 3 || Cout == 4)) {
     const long long total = rows * (Cin >> 2);
     const int gb = g_bf16 ? 1 : 0;
@@ -257,21 +294,21 @@ static int launch_gstack(hipStream_t st, const float* dout, const float* out, co
     return MVH_OK;
   }
   if (g_bf16) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 gradient rows leave the G-stack only through the K = 1 split pass");
-  if (Cin == 16 && Cout == 16 && K <= 12 && rows >= 4096 && !dbg().no_gstack_mfma &&
-      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)W | (uintptr_t)G | (uintptr_t)g0) & 15) == 0) {
+  if (gstack_is_mfma(dout, out, W, G, g0, rows, Cin, Cout, K)) {
     const long long nblk = (rows + 15) / 16;
     const long long waves = min(nblk, 8192ll);
     const long long bpw = (nblk + waves - 1) / waves;
     const int g = (int)((nblk + bpw * 4 - 1) / (bpw * 4));
     const bool relu = act == MVH_ACT_RELU;
 #define MVH_GM(KM, R) \
-  hipLaunchKernelGGL((k_gstack_mfma16<KM, R>), dim3(g), dim3(256), 0, st, dout, out, W, G, g0, rows, K, bpw)
+  hipLaunchKernelGGL((k_gstack_mfma16<KM, R>), dim3(g), dim3(256), 0, st, dout, out, W, G, g0, rows, K, bpw, pmN)
     if (K <= 6) { if (relu) MVH_GM(6, true); else MVH_GM(6, false); }
     else { if (relu) MVH_GM(12, true); else MVH_GM(12, false); }
 #undef MVH_GM
     MVH_LAUNCH_CHECK();
     return MVH_OK;
   }
+  if (pmN) return fail(MVH_ERR_INVALID, "cheb_conv: pair-major G stack outside the matrix-pipe producer");
   const int grid = cdiv(rows, 256);
 #define MVH_G(CT, FULL)                                                                          \
   hipLaunchKernelGGL((k_cheb_gstack<CT, FULL>), dim3(grid), dim3(256), 0, st, dout, out, W, G, g0, \
@@ -417,7 +454,8 @@ template <int TN, int MT, bool RELU>
 __global__ void __launch_bounds__(256)
 k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ dout,
                const float* __restrict__ out, float* __restrict__ partial, long long rows, int Cin, int K,
-               long long rows_per_wave) {
+               long long rows_per_wave, int pmN) {
+  // pmN > 0: the stack planes tx are pair-major [B][Cin/2][pmN][2] (cheb_big.hip); x stays a row-layout tensor
   constexpr int Cout = 16 * TN;
   __shared__ float red[3][MT * TN][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,15 +463,21 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
   const int KC = K * Cin;
   const float* ap[MT];
   float a_load[MT], a_one[MT];  // a = v * a_load + a_one: stack column, ones column (db) or padding
+  bool a_pm[MT];                // this column lives in a pair-major plane
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int kc = ((int)blockIdx.y * MT + t) * 16 + m;
     ap[t] = x;
     a_load[t] = 0.f;
     a_one[t] = 0.f;
+    a_pm[t] = false;
     if (kc < KC) {
       const int k = kc / Cin, ci = kc - k * Cin;
       ap[t] = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin) + ci;
+      if (k > 0 && pmN) {  // element (b, pair, v, c) = b N Cin + pair N 2 + 2 v + c = row Cin - v (Cin - 2) + pair N 2 + c
+        ap[t] = tx + (long long)(k - 1) * rows * Cin + (long long)(ci >> 1) * pmN * 2 + (ci & 1);
+        a_pm[t] = true;
+      }
       a_load[t] = 1.f;
     } else if (kc == KC) {
       a_one[t] = 1.f;
@@ -454,8 +498,10 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
       const long long row_raw = r + 4 * u + q;
       const float live = row_raw < r_end ? 1.f : 0.f;  // (rows_per_wave is a multiple of 16: only the global tail)
       const long long row = min(row_raw, rows - 1);
+      long long off_pm = 0;
+      if (pmN) off_pm = row * Cin - (long long)((int)row % pmN) * (Cin - 2);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[u][t] = fmaf(ap[t][row * Cin], a_load[t], a_one[t]) * live;
+      for (int t = 0; t < MT; ++t) a[u][t] = fmaf(ap[t][a_pm[t] ? off_pm : row * Cin], a_load[t], a_one[t]) * live;
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         float v = dout[row * Cout + n * 16 + m] * live;
@@ -498,13 +544,17 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
 
 static int dw_grid(long long rows) { return (int)min((long long)512, (rows + kDwRows - 1) / kDwRows); }
 
+static bool dw_is_mfma(long long rows, int Cout) { return (Cout == 16 || Cout == 32) && rows >= 4096 && !dbg().no_dw_mfma; }
+
+// pmN > 0 (only where dw_is_mfma holds): the stack planes tx are pair-major (cheb_big.hip)
 static int launch_dw(hipStream_t st, const float* x, const float* tx, const float* dout, const float* out,
                      float* partial, float* dW, float* db, long long rows, int Cin, int Cout, int K,
-                     int act) {
+                     int act, int pmN = 0) {
   const int KC = K * Cin;
   const int n = (KC + 1) * Cout;
   int G = dw_grid(rows);
-  if ((Cout == 16 || Cout == 32) && rows >= 4096 && !dbg().no_dw_mfma) {
+  if (pmN && !dw_is_mfma(rows, Cout)) return fail(MVH_ERR_INVALID, "cheb_conv dW: pair-major stack outside the matrix-pipe kernel");
+  if (dw_is_mfma(rows, Cout)) {
     // big levels: streaming MFMA reduction (k_cheb_dw_mfma); G blocks x 4 waves, contiguous row ranges
     const long long waves = max(4ll, min(2048ll, rows / 256));
     G = min(G, (int)((waves + 3) / 4));
@@ -514,7 +564,7 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
     const bool relu = act == MVH_ACT_RELU;
 #define MVH_DWM(TN, MT, R)                                                                                          \
   hipLaunchKernelGGL((k_cheb_dw_mfma<TN, MT, R>), dim3(G, cdiv(tiles_m, MT)), dim3(256), 0, st, x, tx, dout, out, \
-                     partial, rows, Cin, K, rpw)
+                     partial, rows, Cin, K, rpw, pmN)
     if (Cout == 16) {  // (MT = 6: two passes over dpre instead of three for 11 M-tiles; all 11 at once was slower)
       if (tiles_m <= 2) { if (relu) MVH_DWM(1, 2, true); else MVH_DWM(1, 2, false); }
       else if (tiles_m <= 4 || tiles_m > 12) { if (relu) MVH_DWM(1, 4, true); else MVH_DWM(1, 4, false); }
@@ -544,9 +594,25 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
 }
 
 // ------------------------------------------------------------------ host entry points
+// Layout of the T_k stack of a layer (forward -> contraction, dW; also what tx_saved carries from mvh_cheb_conv_fwd to
+// mvh_cheb_conv_bwd): pair-major planes where cheb_big.hip builds the stack AND both consumers are the kernels that
+// read that layout (16 -> 16 channels on a level of 5120 .. 20480 vertices, i.e. BASELINE configs[3]'s level 0), rows
+// [B][N][Cin] everywhere else.  Returns N for pair-major, 0 for rows.
+static int tx_pair_major(const mvh_csr_t* lap, const float* x, const float* tx, int B, int N, int Cin, int Cout, int K) {
+  if (K < 2 || Cin != 16 || Cout != 16 || !cheb_big_eligible(lap, B, N, Cin, K)) return 0;
+  if (!dw_is_mfma((long long)B * N, Cout) || (((uintptr_t)x | (uintptr_t)tx) & 15) != 0) return 0;
+  return N;
+}
+
 static int tx_forward(hipStream_t st, const mvh_csr_t* lap, const float* x, float* tx, long long plane,
-                      int B, int Cin, int K) {
+                      int B, int Cin, int K, int pmN = 0) {
   // T_1 = L x ; T_k = 2 L T_{k-1} - T_{k-2}   (nn/conv.py:564-569)
+  if (K > 1 && B > 0) {  // 5120 .. 20480 vertices: the whole stack in one launch (cheb_big.hip)
+    bool big = false;
+    if (int rc = try_cheb_big_tx(st, lap, x, tx, B, (int)(plane / ((long long)B * Cin)), Cin, K, pmN != 0, &big)) return rc;
+    if (big) return MVH_OK;
+  }
+  if (pmN) return fail(MVH_ERR_INVALID, "cheb_conv: pair-major stack without the cheb_big kernel");
   for (int k = 1; k < K; ++k) {
     const float* prev = (k == 1) ? x : tx + (long long)(k - 2) * plane;
     const float* prev2 = (k == 1) ? nullptr : (k == 2 ? x : tx + (long long)(k - 3) * plane);
@@ -812,8 +878,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");
     tx = (float*)((char*)ws + kLdsWpackBytes + kSplitScratchBytes);
   }
-  if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K)) return rc;
-  if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act)) return rc;
+  const int pmN = tx_pair_major(lap, x, tx, B, N, Cin, Cout, K);
+  if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K, pmN)) return rc;
+  if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act, false, pmN)) return rc;
   if (pool && pooled)
     if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
   return finish(false);
@@ -1011,11 +1078,12 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
                 N, Cin, Cout, K);
   if (!dw_done) {
     const float* tx = tx_saved;
+    const int pmN = tx_pair_major(lap, x, tx ? tx : tx_ws, B, N, Cin, Cout, K);   // (the forward's rule: same answer)
     if (!tx && K > 1) {
-      if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K)) return rc;
+      if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K, pmN)) return rc;
       tx = tx_ws;
     }
-    if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act)) return rc;
+    if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, rows, Cin, Cout, K, act, pmN)) return rc;
   }
   auto pool_dx = [&]() -> int {  // fallback for dx_pool_t: dx was materialised, pool it with one more launch
     if (dx_pool_t && dx_pooled && dx)
@@ -1051,8 +1119,16 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
                 N, Cin, Cout, K);
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
   float* g0 = (K == 1) ? dx : G;
-  if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act)) return rc;
+  // (the stack is pair-major where cheb_big.hip consumes it and the matrix-pipe kernel produces it)
+  const int g_pm = (K > 1 && cheb_big_eligible(lap_t, B, N, Cin, K) && gstack_is_mfma(dout, out, W, G, g0, rows, Cin, Cout, K)) ? N : 0;
+  if (int rc = launch_gstack(st, dout, out, W, G, g0, rows, Cin, Cout, K, act, false, g_pm)) return rc;
   if (K == 1) return pool_dx();
+  {  // 5120 .. 20480 vertices: the Clenshaw sum over the stack in one launch (cheb_big.hip)
+    bool big = false;
+    if (int rc = try_cheb_big_clenshaw(st, lap_t, G, dx, B, N, Cin, K, g_pm != 0, &big)) return rc;
+    if (big) return pool_dx();
+    if (g_pm) return fail(MVH_ERR_INVALID, "cheb_conv_bwd: pair-major G stack without the cheb_big kernel");
+  }
   for (int k = K - 2; k >= 1; --k) {
     float* bk = G + (long long)k * plane;
     const float* bk2 = (k + 2 < K) ? G + (long long)(k + 2) * plane : nullptr;

@@ -54,6 +54,7 @@ struct DebugCfg {
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping
   int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
   int no_l0h = 0;          // bf16 storage: keep the unpack-and-v_fma form at the 5k level (no cheb_l0h.hip kernel)
+  int no_big = 0;          // levels above 5119 vertices keep the K - 1 SpMM launches (no cheb_big.hip kernel)
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
 };
 DebugCfg& dbg();
@@ -112,6 +113,15 @@ int l0h_pack_dwords(int K);
 int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, bool dry_run, DwReduceEntry* defer);
+// levels too big for the slab kernels (5120 .. 20480 vertices): the whole recurrence of a (mesh, channel pair) in one
+// launch (cheb_big.hip): the T_k stack of the forward / dW, and the Clenshaw sum of a stack G [K][B][N][C] (dX).
+// pm: the stack planes are pair-major [B][C/2][N][2] instead of rows [B][N][C] (what the 16 -> 16 producers / consumers
+// of cheb_conv.hip write / read when cheb_big_eligible holds: contiguous streams for the pair-workgroups)
+bool cheb_big_eligible(const mvh_csr_t* lap, int B, int N, int C, int K);
+int try_cheb_big_tx(hipStream_t st, const mvh_csr_t* lap, const float* x, float* tx, int B, int N, int C, int K, bool pm,
+                    bool* handled);
+int try_cheb_big_clenshaw(hipStream_t st, const mvh_csr_t* lap, const float* G, float* out, int B, int N, int C, int K,
+                          bool pm, bool* handled);
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
                  const float* bias, float* out, int B, int N, int Cin, int Cout, int K, int act, bool bwd,
                  float* wpack /* kLdsWpackBytes of scratch */, bool* handled, const LdsConvOpts& o = LdsConvOpts());

@@ -2,6 +2,8 @@
 // and the reparameterisation (cheb_VAE.py:203-226, 253-258, 270-280, 309-319).
 // These are skinny problems (M = batch), a few MFLOP per mesh; one LDS-tiled fp32 GEMM with
 // generic strides serves forward, dX and dW, and the latent head is one fused kernel per pass.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mvh {
@@ -43,7 +45,7 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
          float* __restrict__ ones_out) {
   // one block = one 16x16 output tile; its 8 waves split K (interleaved 16-chunks) and are
   // summed through LDS in fixed order.  These GEMMs are latency-bound (a few MFLOP): the full
-  // 16-chunks run in a branch-free loop unrolled 4x so four chunks of loads are in flight per
+  // 16-chunks run as branch-free groups of up to eight so that many chunks of loads are in flight per
   // wave; rows/columns past the edge are clamped (their results are never stored) and only
   // the K tail takes the bounds-checked loads.
   // a_mask (same indexing as A): A elements become (mask > 0 ? a * a_scale : 0) on load -- the
@@ -97,25 +99,28 @@ k_gemm16(const float* __restrict__ A, long long sam, long long sak, const float*
   const int NW = blockDim.x >> 6;  // 1..kGemmWaves waves, chosen from K by the launcher
   const int kStep = 16 * NW;
   int k0 = wave * 16;
-  for (; k0 + 3 * kStep < Kfull; k0 += 4 * kStep) {  // four chunks of loads in flight
-    float a[4][4], b[4][4];
+  // this wave's 16-chunks k0, k0 + kStep, ...: the loads of up to eight of them are in flight together (a layer of
+  // K = 640 is five chunks per wave: one memory round trip, not two); the matrix instructions stay in chunk order
+  auto run = [&](auto n_tag) {
+    constexpr int NCH = decltype(n_tag)::value;
+    float a[NCH][4], b[NCH][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_chunk(k0 + u * kStep + 4 * kq, a[u], b[u]);
+    for (int u = 0; u < NCH; ++u) load_chunk(k0 + u * kStep + 4 * kq, a[u], b[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mma(a[u], b[u]);
-  }
-  if (k0 + kStep < Kfull) {  // two
-    float a[2][4], b[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) load_chunk(k0 + u * kStep + 4 * kq, a[u], b[u]);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) mma(a[u], b[u]);
-    k0 += 2 * kStep;
-  }
-  for (; k0 < Kfull; k0 += kStep) {
-    float a[4], b[4];
-    load_chunk(k0 + 4 * kq, a, b);
-    mma(a, b);
+    for (int u = 0; u < NCH; ++u) mma(a[u], b[u]);
+    k0 += NCH * kStep;
+  };
+  int rem = k0 < Kfull ? (Kfull - k0 + kStep - 1) / kStep : 0;
+  for (; rem >= 8; rem -= 8) run(std::integral_constant<int, 8>());
+  switch (rem) {
+    case 7: run(std::integral_constant<int, 7>()); break;
+    case 6: run(std::integral_constant<int, 6>()); break;
+    case 5: run(std::integral_constant<int, 5>()); break;
+    case 4: run(std::integral_constant<int, 4>()); break;
+    case 3: run(std::integral_constant<int, 3>()); break;
+    case 2: run(std::integral_constant<int, 2>()); break;
+    case 1: run(std::integral_constant<int, 1>()); break;
+    default: break;
   }
   if (Kfull < K && wave == ((Kfull >> 4) % NW)) {  // K tail: bounds-checked loads
     float a[4], b[4];

@@ -96,14 +96,27 @@ def _grid_mesh_edges(side):
     return np.vstack([src, dst]).astype(np.int64)
 
 
-def test_cheb_conv_20k_template_k10_matches_oracle():
-    """BASELINE configs[3] shape: a 20k-vertex template with K=10 (too large for the LDS-resident
-    kernels: 142 x 142 = 20164 vertices) against the CPU oracle, forward and all three gradients."""
+@pytest.mark.parametrize("side,B,cin,cout,K,isolated,big", [
+    (142, 2, 16, 16, 10, 0, 1),      # BASELINE configs[3]'s level-0 layer
+    (142, 2, 16, 16, 10, 0, 0),      # ... through the K - 1 SpMM launches (debug switch no_big)
+    (100, 3, 3, 16, 10, 1, 1),       # odd channel count (the first layer), an isolated vertex, B % 8 != 0
+    (100, 3, 16, 3, 4, 2, 1),        # dX / T stack of 16 channels, 3 outputs
+    (143, 1, 16, 16, 2, 0, 1),       # the largest plane that fits (20 449 vertices), K = 2
+])
+def test_cheb_conv_20k_template_k10_matches_oracle(side, B, cin, cout, K, isolated, big):
+    """BASELINE configs[3] shape: a 20k-vertex template with K=10 (too large for the (mesh, 4-channel slab) kernels:
+    142 x 142 = 20164 vertices; csrc/cheb_big.hip runs the recurrence of a channel pair per workgroup) against the
+    CPU oracle, forward and all three gradients."""
+    from meshvae_hip import debug_switch
+    with debug_switch("no_big", 0 if big else 1):
+        _conv_20k_case(side, B, cin, cout, K, isolated)
+
+
+def _conv_20k_case(side, B, cin, cout, K, isolated):
     from nn.conv import ChebConv_batch
     from oracle import cheb_oracle as O
     dev = _dev()
-    side, B, cin, cout, K = 142, 2, 16, 16, 10
-    N = side * side
+    N = side * side + isolated
     ei_cpu = torch.from_numpy(_grid_mesh_edges(side))
     g = torch.Generator().manual_seed(20)
     x = torch.randn(B, N, cin, generator=g)
