@@ -260,7 +260,15 @@ k_gstack_mfma16(const float* __restrict__ dout, const float* __restrict__ out, c
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k].w, d.w, acc, 0, 0, 0);
         float* dst = (k == 0 ? g0 : G + (long long)k * rows * 16);
         if (row_raw < rows) {
-          if (pmN) {
+          if (pmN && (pmN & 1) == 0) {
+            // rows m and m ^ 1 swap halves (pmN even: both in one mesh): the even row's lane then holds pair 2 q of
+            // both rows, the odd one pair 2 q + 1 -- one 16-byte store per lane, 128 contiguous bytes per 8 lanes
+            const bool odd = m & 1;
+            const float rx = __shfl_xor(odd ? acc[0] : acc[2], 1, 64), ry = __shfl_xor(odd ? acc[1] : acc[3], 1, 64);
+            const int rr = (int)row_raw & ~1, b = rr / pmN, v = rr - b * pmN;
+            float2* pp = reinterpret_cast<float2*>(dst) + ((long long)(b * 8 + 2 * q + (odd ? 1 : 0)) * pmN + v);
+            *reinterpret_cast<float4*>(pp) = odd ? make_float4(rx, ry, acc[2], acc[3]) : make_float4(acc[0], acc[1], rx, ry);
+          } else if (pmN) {
             const int rr = (int)row_raw, b = rr / pmN, v = rr - b * pmN;
             float2* pp = reinterpret_cast<float2*>(dst) + ((long long)(b * 8 + 2 * q) * pmN + v);
             pp[0] = make_float2(acc[0], acc[1]);
@@ -493,15 +501,35 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
   const long long r_end = min(rows, r_begin + rows_per_wave);
   for (long long r = r_begin; r < r_end; r += 16) {  // 16 rows per trip: four independent load groups in flight
     float a[4][MT], d[4][TN];
+    if (pmN) {
+      // pair-major columns: the two lanes of a channel pair fetch DIFFERENT rows as float2 (the even channel's lane
+      // the row of instruction 2 h, the odd one's the row of 2 h + 1) and swap halves -- 8 lanes x 8 bytes = one
+      // 64-byte line per pair and instruction, half the loads of the scalar form below
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long long row_mine = min(r + 4 * (2 * h + (m & 1)) + q, rows - 1);
+        const long long off = row_mine * Cin - (long long)((int)row_mine % pmN) * (Cin - 2);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          if (a_pm[t]) {
+            const float2 f = *reinterpret_cast<const float2*>(ap[t] - (m & 1) + off);
+            const float gx = __shfl_xor(f.x, 1, 64), gy = __shfl_xor(f.y, 1, 64);
+            a[2 * h][t] = (m & 1) ? gy : f.x;
+            a[2 * h + 1][t] = (m & 1) ? f.y : gx;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long row_raw = r + 4 * u + q;
       const float live = row_raw < r_end ? 1.f : 0.f;  // (rows_per_wave is a multiple of 16: only the global tail)
       const long long row = min(row_raw, rows - 1);
-      long long off_pm = 0;
-      if (pmN) off_pm = row * Cin - (long long)((int)row % pmN) * (Cin - 2);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[u][t] = fmaf(ap[t][a_pm[t] ? off_pm : row * Cin], a_load[t], a_one[t]) * live;
+      for (int t = 0; t < MT; ++t) {
+        if (pmN && a_pm[t]) a[u][t] *= live;
+        else a[u][t] = fmaf(ap[t][row * Cin], a_load[t], a_one[t]) * live;
+      }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         float v = dout[row * Cout + n * 16 + m] * live;
