@@ -47,7 +47,8 @@ struct DebugCfg {
   int side_prio = 0;       // -1 / +1: low / high queue priority for the weight-gradient lanes
   int no_side = 0;         // 1: weight gradients inline on the main stream
   int no_tstack = 0;       // 1: first-layer dW through the recurrence kernel instead of the saved stack
-  int tail_main = 1;       // 0: encoder layer 1's dW stays on the side lane
+  int tail_main = 0;       // 1: encoder layer 1's dW runs on the main stream after layer 0's (round 1's choice; since the
+                           //    deferred reductions emptied the side lane's backlog the lane is the faster place: 570 vs 576 us)
   int fork_batch = 1;      // conv layers sharing one fork event (1..4)
   int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
   int no_dw_mfma = 0;

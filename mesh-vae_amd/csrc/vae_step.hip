@@ -598,8 +598,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     io.x = bf && i > 0; io.dout = bf && i + 1 < n; io.dx = bf;   // (the last level's gradient comes from the fp32 dense head)
     if (i > 0) {
       // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible);
-      // with the stack path layer 0 costs the main stream only ~10 us, so layer 1's dW runs there after it
-      // instead of at the end of the side lane's backlog (debug switch tail_main = 0: side lane as usual)
+      // debug switch tail_main = 1 puts layer 1's dW on the main stream behind layer 0's instead (round 1's
+      // arrangement, when the side lane still had a backlog at this point)
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]), io,

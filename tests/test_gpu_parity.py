@@ -109,10 +109,10 @@ def test_cheb_conv_20k_template_k10_matches_oracle(side, B, cin, cout, K, isolat
     CPU oracle, forward and all three gradients."""
     from meshvae_hip import debug_switch
     with debug_switch("no_big", 0 if big else 1):
-        _conv_20k_case(side, B, cin, cout, K, isolated)
+        _conv_20k_case(side, B, cin, cout, K, isolated, big)
 
 
-def _conv_20k_case(side, B, cin, cout, K, isolated):
+def _conv_20k_case(side, B, cin, cout, K, isolated, big=1):
     from nn.conv import ChebConv_batch
     from oracle import cheb_oracle as O
     dev = _dev()
@@ -139,6 +139,25 @@ def _conv_20k_case(side, B, cin, cout, K, isolated):
     torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(conv.weight.grad.cpu(), wo.grad, rtol=1e-4, atol=2e-3)   # sums over 40k rows
     torch.testing.assert_close(conv.bias.grad.cpu(), bo.grad, rtol=1e-4, atol=2e-3)
+    if K < 10 or isolated:
+        return
+    # How much of those bars is fp32 itself?  The same layer in float64 (the oracle's code on doubles) is the truth; the
+    # reference's arithmetic (the fp32 oracle) and this library are both measured against it and printed.  Both are
+    # 1e-7-class relative errors; the library's is allowed up to 8 x the reference's own (measured on MI355X: forward
+    # 5.2e-7 against 1.4e-7 -- the recurrence runs in variables scaled by deg^-1/2 and un-scales once at the end).
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    e64, n64 = O.cheb_norm(ei_cpu, N)
+    y64 = O.cheb_conv(x64, e64, n64.double(), w64, b64)
+    y64.backward(gy.double())
+
+    def rel(a, ref):
+        return float((a.double() - ref).norm() / ref.norm())
+    rows = [("y", y.detach().cpu(), yo.detach(), y64.detach()), ("dx", xd.grad.cpu(), xo.grad, x64.grad),
+            ("dW", conv.weight.grad.cpu(), wo.grad, w64.grad), ("db", conv.bias.grad.cpu(), bo.grad, b64.grad)]
+    for name, mine, ref32, truth in rows:
+        e_mine, e_ref = rel(mine, truth), rel(ref32, truth)
+        print(f"[20k layer, big={big}] {name}: |hip - f64| / |f64| = {e_mine:.2e}   |oracle32 - f64| / |f64| = {e_ref:.2e}")
+        assert e_mine <= 8.0 * e_ref + 1e-6, (name, e_mine, e_ref)
 
 
 def test_cheb_conv_fused_relu_and_first_layer(ops_npz, topotiny_npz):
