@@ -4,8 +4,8 @@
 // a whole CU's LDS -- so a workgroup owns (mesh, channel pair):
 //   * LDS   : u_{k-1} of the pair for every vertex as one float2 (+ a zero row N that the padded ELL slots gather);
 //   * VGPRs : u_{k-2} of the thread's own VPT = 20 vertices (vertex v = tid + 1024 j), their degrees (4 bits each);
-//   * the neighbour ids (8 x uint16 per vertex, one 16-byte load) come from the L2-resident ELL list every order,
-//     four vertices' loads in flight, the next four prefetched under the current gathers;
+//   * the neighbour ids (8 x uint16 per vertex, one 16-byte load) come from the L2-resident ELL list every order
+//     through a ring of eight vertices' loads in flight per thread;
 //   * per order: 8 unweighted ds_read_b64 gathers per vertex, then after a barrier each thread swaps its own rows
 //     (registers <-> LDS; MODE 1 adds the order's input piece here, away from the gathers' register pressure) and a
 //     second barrier opens the next order.  HBM sees one read of the input piece or one write of the output piece
@@ -23,7 +23,7 @@
 
 namespace mvh {
 
-constexpr int kBigThreads = 1024, kBigVpt = 20, kBigGroup = 2;
+constexpr int kBigThreads = 1024, kBigVpt = 20, kBigRing = 8;
 
 struct BigArgs {
   const float* in;      // MODE 0: x [B][N][C];  MODE 1: G [K][B][N][C]
@@ -83,6 +83,8 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
     const uint32_t d = v < N ? (a.rowinfo[v] & 255u) : 0u;
     degp[j >> 3] |= d << (4 * (j & 7));
   }
+  // (1/deg, deg^+-1/2 below are the hardware's 1-ulp v_rcp / v_rsq / v_sqrt: the IEEE forms cost a dozen instructions
+  //  and a branch per vertex and order; the degrees are integers <= 8)
   auto deg_of = [&](int j) -> float { return (float)((degp[j >> 3] >> (4 * (j & 7))) & 15u); };
 
   float2 P[kBigVpt];   // u_{k-2} (MODE 1: w_{k+2}) of the own vertices; after an order's first phase the new u_k
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
       const int v = tid + kBigThreads * j;
       P[j] = make_float2(0.f, 0.f);
       if (v < N) {
-        const float dg = deg_of(j), s = dg > 0.f ? rsqrtf(dg) : 1.f;
+        const float dg = deg_of(j), s = dg > 0.f ? __builtin_amdgcn_rsqf(dg) : 1.f;
         const float2 x = big_load2<VEC>(in_m, (unsigned)(v * istr), has1);
         pl[v] = make_float2(s * x.x, s * x.y);
       }
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
       const int v = tid + kBigThreads * j;
       P[j] = make_float2(0.f, 0.f);
       if (v < N) {
-        const float dg = deg_of(j), s = dg > 0.f ? rsqrtf(dg) : 1.f;
+        const float dg = deg_of(j), s = dg > 0.f ? __builtin_amdgcn_rsqf(dg) : 1.f;
         const float2 g = big_load2<VEC>(gk, (unsigned)(v * istr), has1);
         pl[v] = make_float2(s * g.x, s * g.y);
       }
@@ -129,41 +131,37 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
 #pragma unroll
     for (int w = 0; w < (kBigVpt + 7) / 8; ++w) asm volatile("" : "+v"(degp[w]));
     // ---- phase A: P <- -(alpha / deg) sum_nbrs u_{k-1} - P     (MODE 0: = u_k, stored as T_k; MODE 1: = w_k - s G_k)
-    uint4 ids[2][kBigGroup];
-    auto fetch = [&](int g, int buf) {  // ids of the vertices j = g * kBigGroup .. + kBigGroup - 1
+    // neighbour ids: a ring of kBigRing vertices' 16-byte words stays in flight (an order needs 320 KB of them per
+    // workgroup from L2; with two vertices ahead the CU had ~32 KB outstanding and an order took 14 us, all latency)
+    uint4 ring[kBigRing];
 #pragma unroll
-      for (int q = 0; q < kBigGroup; ++q) {
-        const int v = tid_k + kBigThreads * (g * kBigGroup + q);
-        ids[buf][q] = ellv[v < N ? v : N - 1];
+    for (int j = 0; j < kBigRing; ++j) {
+      const int v = tid_k + kBigThreads * j;
+      ring[j] = ellv[v < N ? v : N - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kBigVpt; ++j) {
+      const int v = tid_k + kBigThreads * j;
+      const uint4 id = ring[j % kBigRing];
+      if (j + kBigRing < kBigVpt) {
+        const int vn = tid_k + kBigThreads * (j + kBigRing);
+        ring[j % kBigRing] = ellv[vn < N ? vn : N - 1];
       }
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int g = 0; g < kBigVpt / kBigGroup; ++g) {
-      const int buf = g & 1;
-      if (g + 1 < kBigVpt / kBigGroup) fetch(g + 1, buf ^ 1);
-      __builtin_amdgcn_sched_barrier(0);   // (the unrolled loop must not hoist every group's loads: 80 registers of ids)
-#pragma unroll
-      for (int q = 0; q < kBigGroup; ++q) {
-        const int j = g * kBigGroup + q;
-        const int v = tid_k + kBigThreads * j;
-        if (v < N) {
-          const uint4 id = ids[buf][q];
-          const float2 n0 = pl[id.x & 0xFFFFu], n1 = pl[id.x >> 16], n2 = pl[id.y & 0xFFFFu], n3 = pl[id.y >> 16];
-          const float2 n4 = pl[id.z & 0xFFFFu], n5 = pl[id.z >> 16], n6 = pl[id.w & 0xFFFFu], n7 = pl[id.w >> 16];
-          const float sx = ((n0.x + n1.x) + (n2.x + n3.x)) + ((n4.x + n5.x) + (n6.x + n7.x));
-          const float sy = ((n0.y + n1.y) + (n2.y + n3.y)) + ((n4.y + n5.y) + (n6.y + n7.y));
-          const float dg = deg_of(j);
-          const float coef = dg > 0.f ? -alpha / dg : 0.f;
-          const float2 nu = make_float2(fmaf(coef, sx, -P[j].x), fmaf(coef, sy, -P[j].y));
-          P[j] = nu;
-          if (MODE == 0) {   // T_k = u_k / s
-            const float is = dg > 0.f ? sqrtf(dg) : 1.f;
-            big_store2<VEC>(tk, (unsigned)(v * ostr), has1, make_float2(nu.x * is, nu.y * is));
-          }
+      if (v < N) {
+        const float2 n0 = pl[id.x & 0xFFFFu], n1 = pl[id.x >> 16], n2 = pl[id.y & 0xFFFFu], n3 = pl[id.y >> 16];
+        const float2 n4 = pl[id.z & 0xFFFFu], n5 = pl[id.z >> 16], n6 = pl[id.w & 0xFFFFu], n7 = pl[id.w >> 16];
+        const float sx = ((n0.x + n1.x) + (n2.x + n3.x)) + ((n4.x + n5.x) + (n6.x + n7.x));
+        const float sy = ((n0.y + n1.y) + (n2.y + n3.y)) + ((n4.y + n5.y) + (n6.y + n7.y));
+        const float dg = deg_of(j);
+        const float coef = dg > 0.f ? -alpha * __builtin_amdgcn_rcpf(dg) : 0.f;
+        const float2 nu = make_float2(fmaf(coef, sx, -P[j].x), fmaf(coef, sy, -P[j].y));
+        P[j] = nu;
+        if (MODE == 0) {   // T_k = u_k / s
+          const float is = dg > 0.f ? __builtin_amdgcn_sqrtf(dg) : 1.f;
+          big_store2<VEC>(tk, (unsigned)(v * ostr), has1, make_float2(nu.x * is, nu.y * is));
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled loop from hoisting every vertex's loads: 80 registers)
     }
     if (MODE == 1 && last) {  // out = G_0 + (w_0 - s G_0) / s
 #pragma unroll
@@ -180,7 +178,7 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
           const int j = h * HV + jj2;
           const int v = tid_k + kBigThreads * j;
           if (v < N) {
-            const float dg = deg_of(j), is = dg > 0.f ? sqrtf(dg) : 1.f;
+            const float dg = deg_of(j), is = dg > 0.f ? __builtin_amdgcn_sqrtf(dg) : 1.f;
             big_store2<VEC>(tk, (unsigned)(v * ostr), has1,
                             make_float2(fmaf(P[j].x, is, g0[jj2].x), fmaf(P[j].y, is, g0[jj2].y)));
           }
@@ -211,7 +209,7 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
         if (v < N) {
           float2 nw = P[j];
           if (MODE == 1) {
-            const float dg = deg_of(j), sc = dg > 0.f ? rsqrtf(dg) : 1.f;
+            const float dg = deg_of(j), sc = dg > 0.f ? __builtin_amdgcn_rsqf(dg) : 1.f;
             nw = make_float2(fmaf(sc, gpc[jj2].x, nw.x), fmaf(sc, gpc[jj2].y, nw.y));
           }
           const float2 t = pl[v];

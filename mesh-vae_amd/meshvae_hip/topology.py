@@ -23,28 +23,37 @@ _B128_GROUPS = [np.array(g) for g in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 2
 _B128_GROUPS = _B128_GROUPS + [g + 32 for g in _B128_GROUPS]
 
 
-def conflict_aware_slots(slots, pad, rounds=4):
-    """Permute every vertex's neighbour list (numpy [n_rows, S], `pad` = filler id) so that, for each 16-lane group of
-    the gather and each list slot j, the ids read together fall into distinct word columns (id mod 16) as far as
-    possible; equal ids broadcast for free.  The order of a vertex's neighbours is irrelevant to the unweighted sums
+# ds_read_b64 (the float2 planes of csrc/cheb_big.hip): two 32-lane halves, 8-byte word column = neighbour id mod 32
+_B64_GROUPS = [np.arange(0, 32), np.arange(32, 64)]
+_SLOT_CACHE = {}
+
+
+def conflict_aware_slots(slots, pad, rounds=4, groups=None, ncol=16):
+    """Permute every vertex's neighbour list (numpy [n_rows, S], `pad` = filler id) so that, for each lane group of
+    the gather (default: the four 16-lane groups of ds_read_b128) and each list slot j, the ids read together fall into
+    distinct word columns (id mod ncol) as far as possible; equal ids broadcast for free.  The order of a vertex's neighbours is irrelevant to the unweighted sums
     of the LDS kernels (L is applied in scaled variables), so this is free at run time: on the 5k template the model
     count of LDS cycles per gather instruction drops from 1.99 to 1.15 (1.0 = conflict-free), levels 1-3 alike.
     Method: coordinate descent, one vertex at a time, each step an exact 8 x 8 assignment (Hungarian) of its ids to
     the slots against what the other 15 vertices of its group currently read."""
     n_rows, S = slots.shape
+    groups = _B128_GROUPS if groups is None else groups
+    key = (slots.shape, int(pad), rounds, ncol, len(groups), hash(slots.tobytes()))
+    if key in _SLOT_CACHE:                       # (a process builds the same template many times: tests, micro-batches)
+        return _SLOT_CACHE[key].copy()
     out = slots.copy()
     for w0 in range(0, n_rows, 64):
-        for g in _B128_GROUPS:
+        for g in groups:
             vs = g + w0
             vs = vs[vs < n_rows]
             if vs.size < 2:
                 continue
             rows = [out[v].tolist() for v in vs]
-            usage = [[dict() for _ in range(16)] for _ in range(S)]      # slot -> column -> {id: readers}
+            usage = [[dict() for _ in range(ncol)] for _ in range(S)]    # slot -> column -> {id: readers}
 
             def book(row, sign):
                 for j, u in enumerate(row):
-                    d = usage[j][u & 15]
+                    d = usage[j][u % ncol]
                     n = d.get(u, 0) + sign
                     if n:
                         d[u] = n
@@ -59,7 +68,7 @@ def conflict_aware_slots(slots, pad, rounds=4):
                     cost = np.zeros((S, S))
                     for a, u in enumerate(r):
                         for j in range(S):
-                            d = usage[j][u & 15]
+                            d = usage[j][u % ncol]
                             cost[a, j] = 0 if (not d or u in d) else len(d)
                     ri, ci = linear_sum_assignment(cost)
                     new = [pad] * S
@@ -71,6 +80,7 @@ def conflict_aware_slots(slots, pad, rounds=4):
                 if not changed:
                     break
             out[vs] = np.asarray(rows, dtype=slots.dtype)
+    _SLOT_CACHE[key] = out.copy()
     return out
 
 
@@ -130,6 +140,11 @@ class Csr:
             if self.n_rows == self.n_cols and self.n_rows + 1 <= 5120 and (self.flags & CSR_NORMALIZED_LAPLACIAN):
                 # (only the LDS-resident kernels read the list, and only where edges carry no values)
                 slots = torch.from_numpy(conflict_aware_slots(slots.numpy(), self.n_cols))
+            elif self.n_rows == self.n_cols and self.n_rows <= 20480 and pw == 4 and \
+                    (self.flags & CSR_NORMALIZED_LAPLACIAN) and not (self.flags & CSR_ELL_OVERFLOW):
+                # csrc/cheb_big.hip: float2 planes gathered with ds_read_b64 (32-lane halves, id mod 32)
+                slots = torch.from_numpy(conflict_aware_slots(slots.numpy(), self.n_cols, rounds=2,
+                                                              groups=_B64_GROUPS, ncol=32))
             packed = (slots[:, 0::2] | (slots[:, 1::2] << 16)).contiguous()     # [n_rows, pw] vertex-major
             self.ell = torch.from_numpy(packed.numpy().astype("uint32").view("int32")).to(device)
         self.struct = CsrStruct(self.n_rows, self.n_cols, self.nnz, self.rowptr.data_ptr(),

@@ -144,7 +144,8 @@ def _conv_20k_case(side, B, cin, cout, K, isolated, big=1):
     # How much of those bars is fp32 itself?  The same layer in float64 (the oracle's code on doubles) is the truth; the
     # reference's arithmetic (the fp32 oracle) and this library are both measured against it and printed.  Both are
     # 1e-7-class relative errors; the library's is allowed up to 8 x the reference's own (measured on MI355X: forward
-    # 5.2e-7 against 1.4e-7 -- the recurrence runs in variables scaled by deg^-1/2 and un-scales once at the end).
+    # 2.5e-7 against 1.4e-7 -- the recurrence runs in variables scaled by deg^-1/2 and un-scales once at the end -- dX
+    # 1.4e-7 / 1.5e-7, dW 3.0e-7 / 3.6e-7).
     x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
     e64, n64 = O.cheb_norm(ei_cpu, N)
     y64 = O.cheb_conv(x64, e64, n64.double(), w64, b64)
