@@ -32,6 +32,8 @@ struct BigArgs {
   const uint32_t* rowinfo;  // [N]: (rowptr << 8) | degree
   int B, N, C, K;
   long long plane;      // B * N * C
+  const float* mask;    // MODE 0, optional: rows like `in`; an input element counts only where mask > 0 (ReLU backward)
+  int with_t0;          // MODE 0: the (masked) input itself is stored as plane 0 and T_k as plane k (K planes)
   int pm;               // the stack (MODE 0: tx, MODE 1: G) is PAIR-MAJOR: plane k = [B][C/2][N][2] (C even), so that a
                         // workgroup streams 8 contiguous bytes per vertex instead of 8-byte pieces of 64-byte rows --
                         // with row layout the 8 pair-workgroups of a mesh drift apart, every one of them pulls the whole
@@ -96,8 +98,13 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
       P[j] = make_float2(0.f, 0.f);
       if (v < N) {
         const float dg = deg_of(j), s = dg > 0.f ? __builtin_amdgcn_rsqf(dg) : 1.f;
-        const float2 x = big_load2<VEC>(in_m, (unsigned)(v * istr), has1);
+        float2 x = big_load2<VEC>(in_m, (unsigned)(v * istr), has1);
+        if (a.mask) {
+          const float2 mk = big_load2<VEC>(a.mask + row_base, (unsigned)(v * istr), has1);
+          x = make_float2(mk.x > 0.f ? x.x : 0.f, mk.y > 0.f ? x.y : 0.f);
+        }
         pl[v] = make_float2(s * x.x, s * x.y);
+        if (a.with_t0) big_store2<VEC>(out_m, (unsigned)(v * ostr), has1, x);
       }
     }
   } else {  // w_{K-1} = s G_{K-1}
@@ -123,7 +130,7 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
     const int k = (MODE == 0) ? s : a.K - 1 - s;
     const float alpha = (MODE == 0) ? (k == 1 ? 1.f : 2.f) : (k == 0 ? 1.f : 2.f);
     const float* gk = (MODE == 1) ? in_m + (long long)k * a.plane : nullptr;
-    float* tk = (MODE == 0) ? out_m + (long long)(k - 1) * a.plane : out_m;
+    float* tk = (MODE == 0) ? out_m + (long long)(a.with_t0 ? k : k - 1) * a.plane : out_m;
     // (the thread id and the degrees behind empty asm statements: otherwise the 20 vertices' offsets, LDS addresses,
     //  64-bit list addresses and 1/deg, deg^+-1/2 are hoisted out of the order loop as invariants -- spills)
     int tid_k = tid;
@@ -234,9 +241,9 @@ bool cheb_big_eligible(const mvh_csr_t* lap, int B, int N, int C, int K) {
 
 template <int MODE>
 static int big_launch(hipStream_t st, const mvh_csr_t* lap, const float* in, float* out, int B, int N, int C, int K,
-                      bool pm) {
+                      bool pm, const float* mask = nullptr, bool with_t0 = false) {
   if (pm && (C & 1)) return fail(MVH_ERR_INVALID, "cheb_big: the pair-major stack needs an even channel count");
-  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, pm ? 1 : 0};
+  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, mask, with_t0 ? 1 : 0, pm ? 1 : 0};
   const size_t lds = (size_t)(N + 1) * 8;
   const int grid = ((B + 7) / 8) * 8 * ((C + 1) / 2);
   auto go = [&](auto kern) -> int {
@@ -253,12 +260,13 @@ static int big_launch(hipStream_t st, const mvh_csr_t* lap, const float* in, flo
   return MVH_OK;
 }
 
-// tx[k-1] = T_k(L) x, k = 1 .. K-1 (what tx_forward's K - 1 SpMM launches produce); *handled == false: not eligible
+// tx[k-1] = T_k(L) x, k = 1 .. K-1 (what tx_forward's K - 1 SpMM launches produce); *handled == false: not eligible.
+// mask: x counts only where mask > 0; with_t0: K planes, plane 0 = the (masked) x itself, plane k = T_k
 int try_cheb_big_tx(hipStream_t st, const mvh_csr_t* lap, const float* x, float* tx, int B, int N, int C, int K,
-                    bool pm, bool* handled) {
+                    bool pm, bool* handled, const float* mask, bool with_t0) {
   *handled = false;
   if (!cheb_big_eligible(lap, B, N, C, K)) return MVH_OK;
-  if (int rc = big_launch<0>(st, lap, x, tx, B, N, C, K, pm)) return rc;
+  if (int rc = big_launch<0>(st, lap, x, tx, B, N, C, K, pm, mask, with_t0)) return rc;
   *handled = true;
   return MVH_OK;
 }

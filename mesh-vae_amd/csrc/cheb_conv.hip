@@ -24,7 +24,8 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
                 const float* __restrict__ bias, float* __restrict__ out, long long rows, int Cin,
                 int Cout, int K, int act, int x_bf16, int pmN) {
   // x_bf16: x is stored as bf16 (K == 1 only: the W_eff pass of the split path; the launcher checks)
-  // pmN > 0: the stack planes tx are pair-major [B][8][pmN][2] (cheb_big.hip; 16 -> 16 only, the launcher checks)
+  // pmN != 0: the stack planes tx are pair-major [B][8][|pmN|][2] (cheb_big.hip; 16 -> 16 only, the launcher checks);
+  // pmN < 0: T_0 is plane 0 of that stack as well (x is not read) and T_k plane k -- the backward's T_k(dpre) stack
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float acc[COUT_T];
@@ -33,23 +34,31 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
   if constexpr (VIN && FULL && COUT_T == 16) {
     if (Cin == 16) {  // the stack planes are the kernel's HBM stream: plane k+1 is in flight while plane k is used
       float4 cur[4], nxt[4];
-      {
+      const int pN = pmN < 0 ? -pmN : pmN, koff = pmN < 0 ? 0 : 1;   // stack plane of T_k = k - koff
+      long long pm_off = 0;   // (float2 units) of (mesh, pair 0, vertex) inside a pair-major plane
+      if (pmN) {
+        const int rr = (int)r, b = rr / pN;
+        pm_off = (long long)b * 8 * pN + (rr - b * pN);
+      }
+      if (pmN < 0) {
+        const float2* sp = reinterpret_cast<const float2*>(tx) + pm_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 lo = sp[(long long)(2 * j) * pN], hi = sp[(long long)(2 * j + 1) * pN];
+          cur[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      } else {
         const float4* s0 = reinterpret_cast<const float4*>(x + r * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[j] = s0[j];
       }
-      long long pm_off = 0;   // (float2 units) of (mesh, pair 0, vertex) inside a pair-major plane
-      if (pmN) {
-        const int rr = (int)r, b = rr / pmN;
-        pm_off = (long long)b * 8 * pmN + (rr - b * pmN);
-      }
       for (int k = 0; k < K; ++k) {
         const int kn = min(k + 1, K - 1);  // (the last trip re-reads its own plane: no branch around the loads)
-        if (pmN && kn > 0) {
-          const float2* sp = reinterpret_cast<const float2*>(tx + (long long)(kn - 1) * rows * 16) + pm_off;
+        if (pmN && (kn > 0 || pmN < 0)) {
+          const float2* sp = reinterpret_cast<const float2*>(tx + (long long)(kn - koff) * rows * 16) + pm_off;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float2 lo = sp[(long long)(2 * j) * pmN], hi = sp[(long long)(2 * j + 1) * pmN];
+            const float2 lo = sp[(long long)(2 * j) * pN], hi = sp[(long long)(2 * j + 1) * pN];
             nxt[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
           }
         } else {
@@ -119,7 +128,7 @@ static int launch_contract(hipStream_t st, const float* x, const float* tx, cons
                            const float* bias, float* out, long long rows, int Cin, int Cout, int K,
                            int act, bool x_bf16 = false, int pmN = 0) {
   const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
-  // pmN > 0: pair-major stack planes -- only the 16 -> 16 fast path of the kernel reads them
+  // pmN != 0: pair-major stack planes -- only the 16 -> 16 fast path of the kernel reads them (< 0: T_0 in the stack)
   if (pmN && !(vin && Cin == 16 && Cout == 16)) return fail(MVH_ERR_INVALID, "cheb_conv: pair-major stack outside the 16 -> 16 contraction");
   if (x_bf16 && (!vin || K != 1 || (Cin == 16 && Cout == 16)))
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv: bf16 rows reach the contraction only through the K = 1 split pass");
@@ -619,6 +628,15 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
                      dW, db);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
+}
+
+// Wt[k][co][ci] = W[k][ci][co]
+__global__ void __launch_bounds__(256) k_w_transpose(const float* __restrict__ W, float* __restrict__ Wt, int K, int Cin,
+                                                     int Cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * Cin * Cout) return;
+  const int k = i / (Cin * Cout), rem = i - k * Cin * Cout, co = rem / Cin, ci = rem - co * Cin;
+  Wt[i] = W[((long long)k * Cin + ci) * Cout + co];
 }
 
 // ------------------------------------------------------------------ host entry points
@@ -1145,6 +1163,25 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   if (bf)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dX kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);
+  // 16 -> 16 channels on a level of 5120 .. 20480 vertices (BASELINE configs[3]'s level 0): the INPUT-side form
+  //   dx = sum_k T_k(L^T)(dpre) W_k^T  --  cheb_big.hip's T-stack kernel on the masked dout (pair-major planes, plane 0 =
+  // dpre itself) and the forward's contraction kernel with the transposed weights.  It moves the same bytes as the
+  // output-side form below (G stack out, Clenshaw sum in) but both of its kernels run without scratch: 254 + 228 us
+  // against 290 + 400 us measured in isolation.
+  if (K > 1 && Cin == 16 && Cout == 16 && dx && cheb_big_eligible(lap_t, B, N, Cout, K) &&
+      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)G | (uintptr_t)dx) & 15) == 0 && !dbg().no_dx_tstack &&
+      (size_t)K * Cin * Cout * sizeof(float) <= kSplitScratchBytes) {
+    float* Wt = split;   // [K][Cout][Cin] = W_k^T (the split-path scratch is free on this path)
+    hipLaunchKernelGGL(k_w_transpose, dim3(cdiv(K * Cin * Cout, 256)), dim3(256), 0, st, W, Wt, K, Cin, Cout);
+    MVH_LAUNCH_CHECK();
+    bool big = false;
+    if (int rc = try_cheb_big_tx(st, lap_t, dout, G, B, N, Cout, K, true, &big, act == MVH_ACT_RELU ? out : nullptr, true))
+      return rc;
+    if (big) {
+      if (int rc = launch_contract(st, nullptr, G, Wt, nullptr, dx, rows, Cout, Cin, K, MVH_ACT_NONE, false, -N)) return rc;
+      return pool_dx();
+    }
+  }
   // dx = sum_k T_k(L^T) G_k via Clenshaw: b_k = G_k + 2 L^T b_{k+1} - b_{k+2}; dx = G_0 + L^T b_1 - b_2
   float* g0 = (K == 1) ? dx : G;
   // (the stack is pair-major where cheb_big.hip consumes it and the matrix-pipe kernel produces it)

@@ -56,6 +56,7 @@ struct DebugCfg {
   int no_prefetch = 0;     // mvh_vae_backward_prefetch does nothing (the stack is built inside the backward)
   int no_l0h = 0;          // bf16 storage: keep the unpack-and-v_fma form at the 5k level (no cheb_l0h.hip kernel)
   int no_big = 0;          // levels above 5119 vertices keep the K - 1 SpMM launches (no cheb_big.hip kernel)
+  int no_dx_tstack = 0;    // 16 -> 16 dX on a 5120 .. 20480-vertex level: G stack + Clenshaw kernel instead of T stack + contraction
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
 };
 DebugCfg& dbg();
@@ -120,7 +121,7 @@ int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
 // of cheb_conv.hip write / read when cheb_big_eligible holds: contiguous streams for the pair-workgroups)
 bool cheb_big_eligible(const mvh_csr_t* lap, int B, int N, int C, int K);
 int try_cheb_big_tx(hipStream_t st, const mvh_csr_t* lap, const float* x, float* tx, int B, int N, int C, int K, bool pm,
-                    bool* handled);
+                    bool* handled, const float* mask = nullptr, bool with_t0 = false);
 int try_cheb_big_clenshaw(hipStream_t st, const mvh_csr_t* lap, const float* G, float* out, int B, int N, int C, int K,
                           bool pm, bool* handled);
 int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const float* mask, const float* W,
