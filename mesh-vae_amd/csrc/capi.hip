@@ -37,9 +37,9 @@ static const DebugKey kDebugKeys[] = {
     {"no_dw_mfma", &DebugCfg::no_dw_mfma},       {"no_xcd_remap", &DebugCfg::no_xcd_remap},
     {"no_prefetch", &DebugCfg::no_prefetch},     {"no_l0h", &DebugCfg::no_l0h},
     {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
-    {"no_dx_tstack", &DebugCfg::no_dx_tstack},
+    {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
     {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
-    {"no_dx_tstack", &DebugCfg::no_dx_tstack},
+    {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

@@ -527,9 +527,13 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                           F(p.g_decU[i]), p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, p.pk_dec_b[i], BITS(p.decBits[i]), io,
                           nullptr, &d->up_t[lvl], dst);
     };
-    // (MEASURED, not kept: at the level-0 stage launching this dX BEFORE forking the dW, so that the chip-filling dW
-    //  waits for it, alone or with the dW launch cut into two 128-workgroup halves that leave half the chip to the
-    //  main chain: 576 / 594 us per step against 573 -- the weight-gradient lane then finishes last)
+    // Levels of the streaming kernels (> 5119 vertices, BASELINE configs[3]): this layer's dX and dW are both HBM
+    // streams over ~1 GB; side by side they took 783 + 1044 us (218 + ~500 alone), so the dX goes first and the dW is
+    // forked behind it, under the LDS-resident kernels of the coarser levels.
+    // (At the 5k level the same order was MEASURED and not kept: 576 us per step against 573, and 594 with the dW
+    //  launch cut into two 128-workgroup halves -- the weight-gradient lane then finishes last.)
+    const bool dx_first = p.Nn[lvl] + 1 > 5120 && !dbg().no_dx_first;
+    if (dx_first) TRY(dx_this());
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
                      p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));
@@ -548,7 +552,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       }
       side->tstack_pending = false;
     }
-    TRY(dx_this());
+    if (!dx_first) TRY(dx_this());
   }
   // ---- dense decoder head, latent heads, dense encoder head: the dX chain stays on the main stream,
   //      every weight gradient (4 GEMMs + the head gradients) goes to the dense lane after ONE fork
