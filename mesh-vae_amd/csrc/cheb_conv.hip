@@ -427,30 +427,32 @@ k_cheb_dw(const float* __restrict__ x, const float* __restrict__ tx, const float
 }
 
 // out[i] = sum_g partial[g][i] in fixed order; first n_w entries go to dW, the rest to db.
-// 64 outputs per block; its 4 waves take interleaved quarters of the G partials with four independent chains
-// each (512 dependent loads per output in one thread took 120 us at the 20k level), combined through LDS.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_reduce_partials(const float* __restrict__ partial, int G, int n, int n_w, float* __restrict__ dW,
                   float* __restrict__ db) {
-  __shared__ float red[3][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // 64 outputs per block, NW = blockDim / 64 waves (4 or 16): wave w sums the partials g = w, w + NW, ... with four
+  // independent chains, then wave 0 adds the waves' sums in wave order.  (16 waves where G is large: with 4, an
+  // output was 32 dependent load rounds deep -- 126 us for the 496 outputs of the 20k first layer, at the very end
+  // of the step's critical path.)
+  __shared__ float red[15][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int g = w;
-    for (; g + 12 < G; g += 16) {
+    for (; g + 3 * NW < G; g += 4 * NW) {
       s0 += partial[(long long)g * n + i];
-      s1 += partial[(long long)(g + 4) * n + i];
-      s2 += partial[(long long)(g + 8) * n + i];
-      s3 += partial[(long long)(g + 12) * n + i];
+      s1 += partial[(long long)(g + NW) * n + i];
+      s2 += partial[(long long)(g + 2 * NW) * n + i];
+      s3 += partial[(long long)(g + 3 * NW) * n + i];
     }
-    for (; g < G; g += 4) s0 += partial[(long long)g * n + i];
+    for (; g < G; g += NW) s0 += partial[(long long)g * n + i];
   }
   float s = (s0 + s1) + (s2 + s3);
   if (w > 0) red[w - 1][lane] = s;
   __syncthreads();
   if (w == 0 && i < n) {
-    s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+    for (int u = 1; u < NW; ++u) s += red[u - 1][lane];
     if (i < n_w) dW[i] = s;
     else if (db) db[i - n_w] = s;
   }
@@ -624,7 +626,7 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
                        Cout, K, act, TI, TJ, nchunks);
     MVH_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 64)), dim3(256), 0, st, partial, G, n, KC * Cout,
+  hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 64)), dim3(G >= 128 ? 1024 : 256), 0, st, partial, G, n, KC * Cout,
                      dW, db);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
