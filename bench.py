@@ -198,11 +198,18 @@ def conv_ops(net, B, dev, dtype="f32"):
         db = torch.empty(Cout, device=dev) if relu else None
         use_signs = relu and Cout % 4 == 0 and K > 1
         signs = torch.empty(B, N, max(Cout // 4, 1), dtype=torch.uint8, device=dev)
-        keep = (x, out, dout, W, bias, dW, dx, db, signs, ws)
+        # levels of the streaming kernels (> 5119 vertices, fp32): the step's forward SAVES the T_k stack for the weight
+        # gradient (vae_step.hip, txEnc / txDec); the isolated ops do the same through the tx_saved argument of the plain
+        # entry points, so that "conv dW" is timed without rebuilding the stack
+        tx = None
+        if N + 1 > 5120 and not half and K > 1:
+            tx = torch.empty((K - 1) * B * N * Cin, device=dev)
+            use_signs = False
+        keep = (x, out, dout, W, bias, dW, dx, db, signs, ws, tx)
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 
         def fwd(lap=lap, x=x, W=W, bias=bias, out=out, signs=signs, N=N, Cin=Cin, Cout=Cout, K=K, ws=ws, ws_b=ws_b,
-                use_signs=use_signs, relu=relu, half=half, act=act):
+                use_signs=use_signs, relu=relu, half=half, act=act, tx=tx):
             if half:
                 check(L.mvh_cheb_conv_fwd_bf16(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(signs) if relu else None, B, N,
                                                Cin, Cout, K, act, p(ws), ws_b))
@@ -210,11 +217,11 @@ def conv_ops(net, B, dev, dtype="f32"):
                 check(L.mvh_cheb_conv_fwd_signs(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(signs), B, N, Cin, Cout,
                                                 K, p(ws), ws_b))
             else:
-                check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), None, B, N, Cin, Cout, K,
+                check(L.mvh_cheb_conv_fwd(st, lap.fwd.ref, p(x), p(W), p(bias), p(out), p(tx), B, N, Cin, Cout, K,
                                           int(relu), p(ws), ws_b))
 
         def bwd(want_dx, want_dw, lap=lap, x=x, W=W, out=out, signs=signs, dout=dout, dx=dx, dW=dW, db=db, N=N, Cin=Cin,
-                Cout=Cout, K=K, ws=ws, ws_b=ws_b, use_signs=use_signs, relu=relu, half=half, act=act):
+                Cout=Cout, K=K, ws=ws, ws_b=ws_b, use_signs=use_signs, relu=relu, half=half, act=act, tx=tx):
             a_dx, a_dw, a_db = (p(dx) if want_dx else None), (p(dW) if want_dw else None), (p(db) if want_dw else None)
             if half:
                 check(L.mvh_cheb_conv_bwd_bf16(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(signs) if relu else None, p(dout),
@@ -223,7 +230,7 @@ def conv_ops(net, B, dev, dtype="f32"):
                 check(L.mvh_cheb_conv_bwd_signs(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(signs), p(dout), a_dx,
                                                 a_dw, a_db, B, N, Cin, Cout, K, p(ws), ws_b))
             else:
-                check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(dout), None, a_dx, a_dw,
+                check(L.mvh_cheb_conv_bwd(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), p(out), p(dout), p(tx), a_dx, a_dw,
                                           a_db, B, N, Cin, Cout, K, int(relu), p(ws), ws_b))
         fwd()                                    # forward once: valid `out` / signs for the backward closures
         pin, pout = B * N * Cin * esize, B * N * Cout * esize
