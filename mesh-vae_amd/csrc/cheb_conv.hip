@@ -632,6 +632,132 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
   return MVH_OK;
 }
 
+// ------------------------------------------------------------------ 16 -> 16 backward on a streaming level, one pass
+// BASELINE configs[3]'s level-0 layer: both gradients that need the Chebyshev stack from ONE pass over
+//   S_k = T_k(L)(dpre)   (K pair-major planes from cheb_big.hip; plane 0 = dpre = dout masked by the forward output):
+//   dx    = sum_k S_k W_k^T                       (the input-side form of the dX)
+//   dW_k  = x^T S_k,  db = column sums of S_0     (L is symmetric: <T_k x, dpre> = <x, T_k dpre>)
+// so the 0.8 GB stack is read once instead of once by the contraction and once by the weight-gradient kernel (which
+// also shut each other out of the CUs when they ran side by side), and the forward's own T_k(x) stack is not needed
+// by the backward at all.  A wave walks a contiguous row range 16 rows per trip, everything on v_mfma_f32_16x16x4_f32:
+//   dW_k tile [ci x co] += x^T[ci x 4 rows] S_k[4 rows x co]     A = x[r + 4 u + q][m], B = S_k[r + 4 u + q][m]
+//   dx tile [16 rows x ci] += S_k[16 rows x 4 co] W_k^T[4 co x ci]   A = S_k[r + m][4 j + q], B = Wt_k[4 j + q][m] (LDS)
+// The pair-major B operand of the first product is fetched as float2 by the two lanes of a channel pair from two
+// different rows and swapped (as in k_cheb_dw_mfma); the partial tiles leave in k_reduce_partials' layout.
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+k_big_bwd16(const float* __restrict__ S, const float* __restrict__ x, const float* __restrict__ Wt,
+            float* __restrict__ dx, float* __restrict__ partial, long long rows, int N, int K, long long rows_per_wave) {
+  extern __shared__ __align__(16) float bsm[];
+  float* wl = bsm;                                   // [K][16 co][16 ci]
+  float* red = bsm + KMAX * 256;                     // [3][KMAX + 1][64][4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  for (int i = threadIdx.x; i < K * 256; i += blockDim.x) wl[i] = Wt[i];
+  __syncthreads();
+  f32x4_t acc_w[KMAX], acc_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc_w[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const long long plane = rows * 16;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  const long long r_begin = wid * rows_per_wave;
+  const long long r_end = min(rows, r_begin + rows_per_wave);
+  // element (row, channel c) of a pair-major plane = row * 16 - (row % N) * 14 + (c / 2) * 2 N + (c & 1)
+  const long long pair_off = (long long)(m >> 1) * N * 2;   // this lane's pair as the B operand of the dW product
+  for (long long r = r_begin; r < r_end; r += 16) {
+    float ax[4], live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long row_raw = r + 4 * u + q;
+      live[u] = row_raw < r_end ? 1.f : 0.f;
+      ax[u] = x[min(row_raw, rows - 1) * 16 + m] * live[u];
+    }
+    // offsets of the rows this lane fetches for the dW product: h = 0 -> instruction 2 h + (m & 1)
+    long long off_w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long row_mine = min(r + 4 * (2 * h + (m & 1)) + q, rows - 1);
+      off_w[h] = row_mine * 16 - (long long)((int)row_mine % N) * 14 + pair_off;
+    }
+    // ... and of the row it feeds to the dX product (A operand: row r + m, channels 4 j + q)
+    const long long row_x = min(r + m, rows - 1);
+    const long long off_x = row_x * 16 - (long long)((int)row_x % N) * 14;
+    f32x4_t acc_x = {0.f, 0.f, 0.f, 0.f};
+    // plane k + 2's operands are in flight while plane k is multiplied (two waves per SIMD: the latency of the
+    // per-plane loads is otherwise a dozen serial global round trips per trip)
+    constexpr int PF = 2;
+    float2 fw[PF + 1][2];
+    float fa[PF + 1][4];
+    auto fetch = [&](int k, int slot) {
+      const float* pk = S + (long long)k * plane;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) fw[slot][h] = *reinterpret_cast<const float2*>(pk + off_w[h]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + q;
+        fa[slot][j] = pk[off_x + (long long)(c >> 1) * N * 2 + (c & 1)];
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < K) fetch(k, k % (PF + 1));
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        if (k + PF < K) fetch(k + PF, (k + PF) % (PF + 1));
+        const int slot = k % (PF + 1);
+        float bs[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float2 f = fw[slot][h];
+          const float gx = __shfl_xor(f.x, 1, 64), gy = __shfl_xor(f.y, 1, 64);
+          bs[2 * h] = (m & 1) ? gy : f.x;
+          bs[2 * h + 1] = (m & 1) ? f.y : gx;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc_w[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], bs[u], acc_w[k], 0, 0, 0);
+        if (k == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(live[u], bs[u], acc_b, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc_x = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][j], wl[(k * 16 + 4 * j + q) * 16 + m], acc_x, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // dx tile: lane (ci = m, q) holds the rows r + 4 q + j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long row = r + 4 * q + j;
+      if (row < r_end) dx[row * 16 + m] = acc_x[j];
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(((wave - 1) * (KMAX + 1) + k) * 64 + lane) * 4 + j] = acc_w[k][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(((wave - 1) * (KMAX + 1) + KMAX) * 64 + lane) * 4 + j] = acc_b[j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* p = partial + (long long)blockIdx.x * (K * 16 + 1) * 16;
+    auto total = [&](float v, int t, int j) {
+      return ((v + red[((0 * (KMAX + 1) + t) * 64 + lane) * 4 + j]) + red[((1 * (KMAX + 1) + t) * 64 + lane) * 4 + j]) +
+             red[((2 * (KMAX + 1) + t) * 64 + lane) * 4 + j];
+    };
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[(long long)(k * 16 + 4 * q + j) * 16 + m] = total(acc_w[k][j], k, j);  // [ci = 4 q + j][co = m]
+      }
+    if (q == 0) p[(long long)(K * 16) * 16 + m] = total(acc_b[0], KMAX, 0);   // every row of the ones tile is db
+  }
+}
+
 // Wt[k][co][ci] = W[k][ci][co]
 __global__ void __launch_bounds__(256) k_w_transpose(const float* __restrict__ W, float* __restrict__ Wt, int K, int Cin,
                                                      int Cout) {
@@ -1063,6 +1189,39 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   }
   bool dw_done = (dW == nullptr);  // dW == NULL: dX-only call (the step engine runs dW on a side stream)
   bool dx_done = (dx == nullptr);
+  // 16 -> 16 on a level of 5120 .. 20480 vertices with BOTH gradients asked for: one T_k(dpre) stack, one pass over it
+  // (k_big_bwd16); the forward's stack (tx_saved) is not read
+  if (dW && dx && K > 1 && K <= 12 && Cin == 16 && Cout == 16 && cheb_big_eligible(lap_t, B, N, Cout, K) &&
+      (lap->flags & MVH_CSR_SYMMETRIC) && (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)G | (uintptr_t)dx | (uintptr_t)x) & 15) == 0 &&
+      !dbg().no_dx_tstack && !dbg().no_bwd_fused && rows >= 4096) {
+    float* Wt = split;   // [K][Cout][Cin] = W_k^T
+    hipLaunchKernelGGL(k_w_transpose, dim3(cdiv(K * Cin * Cout, 256)), dim3(256), 0, st, W, Wt, K, Cin, Cout);
+    MVH_LAUNCH_CHECK();
+    bool big = false;
+    if (int rc = try_cheb_big_tx(st, lap_t, dout, G, B, N, Cout, K, true, &big, act == MVH_ACT_RELU ? out : nullptr, true))
+      return rc;
+    if (big) {
+      int Gb = dw_grid(rows);
+      const long long waves = max(4ll, min(2048ll, rows / 256));
+      Gb = min(Gb, (int)((waves + 3) / 4));
+      long long rpw = (rows + (long long)Gb * 4 - 1) / ((long long)Gb * 4);
+      rpw = (rpw + 15) / 16 * 16;
+      const int n = (K * 16 + 1) * 16;
+      if (K <= 6) {
+        const size_t lds = (size_t)(6 * 256 + 3 * 7 * 256) * sizeof(float);
+        hipLaunchKernelGGL((k_big_bwd16<6>), dim3(Gb), dim3(256), lds, st, G, x, Wt, dx, partial, rows, N, K, rpw);
+      } else {
+        const size_t lds = (size_t)(12 * 256 + 3 * 13 * 256) * sizeof(float);
+        hipLaunchKernelGGL((k_big_bwd16<12>), dim3(Gb), dim3(256), lds, st, G, x, Wt, dx, partial, rows, N, K, rpw);
+      }
+      MVH_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(n, 64)), dim3(Gb >= 128 ? 1024 : 256), 0, st, partial, Gb, n, K * 256, dW, db);
+      MVH_LAUNCH_CHECK();
+      if (dx_pool_t && dx_pooled)
+        return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+      return MVH_OK;
+    }
+  }
   const bool split_ok = !tx_saved && split_eligible(lap, N, Cin, Cout, K) && split_eligible(lap_t, N, Cin, Cout, K);
   const int CC = Cin * Cout;
   if (split_ok && !dw_done) {  // dW_k = dWsub_k + c_k (S_all - dWsub_0), see k_dw_combine

@@ -58,6 +58,7 @@ struct DebugCfg {
   int no_big = 0;          // levels above 5119 vertices keep the K - 1 SpMM launches (no cheb_big.hip kernel)
   int no_dx_tstack = 0;    // 16 -> 16 dX on a 5120 .. 20480-vertex level: G stack + Clenshaw kernel instead of T stack + contraction
   int no_dx_first = 0;     // streaming levels: fork a decoder stage's dW before (not behind) its dX, as at the small levels
+  int no_bwd_fused = 0;    // ... and its dW / dX as two kernels reading two stacks instead of one pass over T_k(dpre)
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
 };
 DebugCfg& dbg();

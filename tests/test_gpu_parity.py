@@ -100,6 +100,7 @@ def _grid_mesh_edges(side):
     (142, 2, 16, 16, 10, 0, 1),      # BASELINE configs[3]'s level-0 layer
     (142, 2, 16, 16, 10, 0, 0),      # ... through the K - 1 SpMM launches (debug switch no_big)
     (142, 2, 16, 16, 10, 0, 2),      # ... with the output-side dX (G stack + Clenshaw kernel, debug switch no_dx_tstack)
+    (142, 2, 16, 16, 10, 0, 3),      # ... with dX and dW as two kernels over two stacks (debug switch no_bwd_fused)
     (100, 3, 3, 16, 10, 1, 1),       # odd channel count (the first layer), an isolated vertex, B % 8 != 0
     (100, 3, 16, 3, 4, 2, 1),        # dX / T stack of 16 channels, 3 outputs
     (143, 1, 16, 16, 2, 0, 1),       # the largest plane that fits (20 449 vertices), K = 2
@@ -109,7 +110,8 @@ def test_cheb_conv_20k_template_k10_matches_oracle(side, B, cin, cout, K, isolat
     142 x 142 = 20164 vertices; csrc/cheb_big.hip runs the recurrence of a channel pair per workgroup) against the
     CPU oracle, forward and all three gradients."""
     from meshvae_hip import debug_switch
-    with debug_switch("no_big", 0 if big else 1), debug_switch("no_dx_tstack", 1 if big == 2 else 0):
+    with debug_switch("no_big", 0 if big else 1), debug_switch("no_dx_tstack", 1 if big == 2 else 0), \
+            debug_switch("no_bwd_fused", 1 if big == 3 else 0):
         _conv_20k_case(side, B, cin, cout, K, isolated, big)
 
 
