@@ -473,13 +473,18 @@ template <int TN, int MT, bool RELU>
 __global__ void __launch_bounds__(256)
 k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ dout,
                const float* __restrict__ out, float* __restrict__ partial, long long rows, int Cin, int K,
-               long long rows_per_wave, int pmN) {
+               long long rows_per_wave, int pmN, const int* __restrict__ sel, int selN, int fullN) {
   // pmN > 0: the stack planes tx are pair-major [B][Cin/2][pmN][2] (cheb_big.hip); x stays a row-layout tensor
+  // sel != NULL: dout is the gradient of the POOLED output [B][selN][Cout] (one-hot downsampling, nn/pool.py D): the
+  // un-pooled gradient is zero everywhere else, so the reduction runs over the B * selN pooled rows only (`rows`
+  // counts those); row (b, v') reads x / T_k / the ReLU mask at the fine vertex (b, sel[v']) of a mesh of fullN rows
+  // -- the scatter into zeros of the reference's autograd, its pool launch and 3/4 of the matrix work disappear
   constexpr int Cout = 16 * TN;
   __shared__ float red[3][MT * TN][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int KC = K * Cin;
+  const long long plane_rows = sel ? (rows / selN) * fullN : rows;   // rows of one stack plane
   const float* ap[MT];
   float a_load[MT], a_one[MT];  // a = v * a_load + a_one: stack column, ones column (db) or padding
   bool a_pm[MT];                // this column lives in a pair-major plane
@@ -492,9 +497,9 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
     a_pm[t] = false;
     if (kc < KC) {
       const int k = kc / Cin, ci = kc - k * Cin;
-      ap[t] = (k == 0 ? x : tx + (long long)(k - 1) * rows * Cin) + ci;
+      ap[t] = (k == 0 ? x : tx + (long long)(k - 1) * plane_rows * Cin) + ci;
       if (k > 0 && pmN) {  // element (b, pair, v, c) = b N Cin + pair N 2 + 2 v + c = row Cin - v (Cin - 2) + pair N 2 + c
-        ap[t] = tx + (long long)(k - 1) * rows * Cin + (long long)(ci >> 1) * pmN * 2 + (ci & 1);
+        ap[t] = tx + (long long)(k - 1) * plane_rows * Cin + (long long)(ci >> 1) * pmN * 2 + (ci & 1);
         a_pm[t] = true;
       }
       a_load[t] = 1.f;
@@ -536,15 +541,20 @@ k_cheb_dw_mfma(const float* __restrict__ x, const float* __restrict__ tx, const 
       const long long row_raw = r + 4 * u + q;
       const float live = row_raw < r_end ? 1.f : 0.f;  // (rows_per_wave is a multiple of 16: only the global tail)
       const long long row = min(row_raw, rows - 1);
+      long long frow = row;   // the row of x / T_k / out
+      if (sel) {
+        const int rr = (int)row, b = rr / selN;
+        frow = (long long)b * fullN + sel[rr - b * selN];
+      }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         if (pmN && a_pm[t]) a[u][t] *= live;
-        else a[u][t] = fmaf(ap[t][row * Cin], a_load[t], a_one[t]) * live;
+        else a[u][t] = fmaf(ap[t][frow * Cin], a_load[t], a_one[t]) * live;
       }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         float v = dout[row * Cout + n * 16 + m] * live;
-        if constexpr (RELU) v = out[row * Cout + n * 16 + m] > 0.f ? v : 0.f;
+        if constexpr (RELU) v = out[frow * Cout + n * 16 + m] > 0.f ? v : 0.f;
         d[u][n] = v;
       }
     }
@@ -588,11 +598,13 @@ static bool dw_is_mfma(long long rows, int Cout) { return (Cout == 16 || Cout ==
 // pmN > 0 (only where dw_is_mfma holds): the stack planes tx are pair-major (cheb_big.hip)
 static int launch_dw(hipStream_t st, const float* x, const float* tx, const float* dout, const float* out,
                      float* partial, float* dW, float* db, long long rows, int Cin, int Cout, int K,
-                     int act, int pmN = 0) {
+                     int act, int pmN = 0, const int* sel = nullptr, int selN = 0, int fullN = 0) {
   const int KC = K * Cin;
   const int n = (KC + 1) * Cout;
   int G = dw_grid(rows);
-  if (pmN && !dw_is_mfma(rows, Cout)) return fail(MVH_ERR_INVALID, "cheb_conv dW: pair-major stack outside the matrix-pipe kernel");
+  if ((pmN || sel) && !dw_is_mfma(rows, Cout))
+    return fail(MVH_ERR_INVALID, "cheb_conv dW: pair-major stack / pooled-row list outside the matrix-pipe kernel");
+  if (pmN && sel) return fail(MVH_ERR_INVALID, "cheb_conv dW: pooled-row list over a pair-major stack");
   if (dw_is_mfma(rows, Cout)) {
     // big levels: streaming MFMA reduction (k_cheb_dw_mfma); G blocks x 4 waves, contiguous row ranges
     const long long waves = max(4ll, min(2048ll, rows / 256));
@@ -603,7 +615,7 @@ static int launch_dw(hipStream_t st, const float* x, const float* tx, const floa
     const bool relu = act == MVH_ACT_RELU;
 #define MVH_DWM(TN, MT, R)                                                                                          \
   hipLaunchKernelGGL((k_cheb_dw_mfma<TN, MT, R>), dim3(G, cdiv(tiles_m, MT)), dim3(256), 0, st, x, tx, dout, out, \
-                     partial, rows, Cin, K, rpw, pmN)
+                     partial, rows, Cin, K, rpw, pmN, sel, selN, fullN)
     if (Cout == 16) {  // (MT = 6: two passes over dpre instead of three for 11 M-tiles; all 11 at once was slower)
       if (tiles_m <= 2) { if (relu) MVH_DWM(1, 2, true); else MVH_DWM(1, 2, false); }
       else if (tiles_m <= 4 || tiles_m > 12) { if (relu) MVH_DWM(1, 4, true); else MVH_DWM(1, 4, false); }
@@ -1156,6 +1168,21 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     // reference's autograd) is folded into the loads of the LDS kernels; all or nothing.
     MVH_REQUIRE(fused_ok != nullptr, "cheb_conv_bwd: fused_ok required with dout_pool");
     *fused_ok = false;
+    if (dW && !dx && (dout_pool->flags & MVH_CSR_SELECTION) && dout_pool->col && K > 1 && N + 1 > 5120 && !bf &&
+        dw_is_mfma((long long)B * dout_pool->n_rows, Cout) && !dbg().force_generic && !dbg().no_dw_rows &&
+        tx_pair_major(lap, x, tx_saved ? tx_saved : tx_ws, B, N, Cin, Cout, K) == 0) {
+      // streaming level (BASELINE configs[3]'s first layer): the matrix-pipe weight-gradient kernel walks the pooled
+      // rows only -- no un-pooling launch, a quarter of the reduction
+      const float* tx = tx_saved;
+      if (!tx) {
+        if (int rc = tx_forward(st, lap, x, tx_ws, plane, B, Cin, K, 0)) return rc;
+        tx = tx_ws;
+      }
+      if (int rc = launch_dw(st, x, tx, dout, out, partial, dW, db, (long long)B * dout_pool->n_rows, Cin, Cout, K, act, 0,
+                             dout_pool->col, dout_pool->n_rows, N)) return rc;
+      *fused_ok = true;
+      return MVH_OK;
+    }
     if (tx_saved || !dout_pool->sel_inv) return MVH_OK;
     const float* mask = act == MVH_ACT_RELU ? out : nullptr;
     size_t pbytes = (size_t)((char*)ws + ws_bytes - (char*)partial);

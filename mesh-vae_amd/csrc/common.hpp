@@ -59,6 +59,7 @@ struct DebugCfg {
   int no_dx_tstack = 0;    // 16 -> 16 dX on a 5120 .. 20480-vertex level: G stack + Clenshaw kernel instead of T stack + contraction
   int no_dx_first = 0;     // streaming levels: fork a decoder stage's dW before (not behind) its dX, as at the small levels
   int no_bwd_fused = 0;    // ... and its dW / dX as two kernels reading two stacks instead of one pass over T_k(dpre)
+  int no_dw_rows = 0;      // streaming levels: un-pool the gradient with its own launch, reduce the weight gradient over all rows
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
 };
 DebugCfg& dbg();
