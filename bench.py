@@ -202,7 +202,7 @@ def conv_ops(net, B, dev, dtype="f32"):
         # gradient (vae_step.hip, txEnc / txDec); the isolated ops do the same through the tx_saved argument of the plain
         # entry points, so that "conv dW" is timed without rebuilding the stack
         tx = None
-        if N + 1 > 5120 and not half and K > 1:
+        if N + 1 > 5120 and not half and K > 1 and label != "final":   # (the final layer takes the split path: no stack)
             tx = torch.empty((K - 1) * B * N * Cin, device=dev)
             use_signs = False
         keep = (x, out, dout, W, bias, dW, dx, db, signs, ws, tx)
