@@ -104,6 +104,7 @@ def _grid_mesh_edges(side):
     (100, 3, 3, 16, 10, 1, 1),       # odd channel count (the first layer), an isolated vertex, B % 8 != 0
     (100, 3, 16, 3, 4, 2, 1),        # dX / T stack of 16 channels, 3 outputs
     (143, 1, 16, 16, 2, 0, 1),       # the largest plane that fits (20 449 vertices), K = 2
+    (100, 3, 16, 16, 4, 1, 1),       # the K <= 6 instance of the two-gradient kernel, an isolated vertex, B = 3
 ])
 def test_cheb_conv_20k_template_k10_matches_oracle(side, B, cin, cout, K, isolated, big):
     """BASELINE configs[3] shape: a 20k-vertex template with K=10 (too large for the (mesh, 4-channel slab) kernels:
