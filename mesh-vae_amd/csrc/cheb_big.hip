@@ -45,11 +45,14 @@ __device__ __forceinline__ float2 big_load2(const float* p, unsigned idx, bool h
   if (VEC) return *reinterpret_cast<const float2*>(p + idx);
   return make_float2(p[idx], has1 ? p[idx + 1] : 0.f);
 }
+// (nontemporal: the stack planes are written once and read after the whole 0.8 GB stack has passed -- keeping them out
+//  of L2 took the T kernel from 238 to 212 us and its consumers' re-reads of x / weights stay cached)
 template <bool VEC>
 __device__ __forceinline__ void big_store2(float* p, unsigned idx, bool has1, float2 v) {
   if (VEC) {
-    *reinterpret_cast<float2*>(p + idx) = v;
-  } else {
+    typedef float f2nt __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store((f2nt){v.x, v.y}, reinterpret_cast<f2nt*>(p + idx));
+  } else {   // (4-byte pieces of 12-byte rows: plain stores -- nontemporal ones took the 3-channel launch from 108 to 168 us)
     p[idx] = v.x;
     if (has1) p[idx + 1] = v.y;
   }

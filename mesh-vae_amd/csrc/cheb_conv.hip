@@ -15,6 +15,8 @@
 
 namespace mvh {
 
+typedef float f2nt_c __attribute__((ext_vector_type(2)));
+typedef float f4nt_c __attribute__((ext_vector_type(4)));
 static bool dw_is_mfma(long long rows, int Cout);
 
 // ------------------------------------------------------------------ forward contraction
@@ -55,10 +57,12 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
       for (int k = 0; k < K; ++k) {
         const int kn = min(k + 1, K - 1);  // (the last trip re-reads its own plane: no branch around the loads)
         if (pmN && (kn > 0 || pmN < 0)) {
-          const float2* sp = reinterpret_cast<const float2*>(tx + (long long)(kn - koff) * rows * 16) + pm_off;
+          // (streamed once: nontemporal, so that 0.8 GB of stack do not sweep L2)
+          const f2nt_c* sp = reinterpret_cast<const f2nt_c*>(tx + (long long)(kn - koff) * rows * 16) + pm_off;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float2 lo = sp[(long long)(2 * j) * pN], hi = sp[(long long)(2 * j + 1) * pN];
+            const f2nt_c lo = __builtin_nontemporal_load(sp + (long long)(2 * j) * pN);
+            const f2nt_c hi = __builtin_nontemporal_load(sp + (long long)(2 * j + 1) * pN);
             nxt[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
           }
         } else {
@@ -704,10 +708,11 @@ k_big_bwd16(const float* __restrict__ S, const float* __restrict__ x, const floa
       const float* pk = S + (long long)k * plane;
 #pragma unroll
       for (int h = 0; h < 2; ++h) fw[slot][h] = *reinterpret_cast<const float2*>(pk + off_w[h]);
+      // (plain loads: the dX operands below touch the same lines a second time -- nontemporal ones here cost 16 us)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = 4 * j + q;
-        fa[slot][j] = pk[off_x + (long long)(c >> 1) * N * 2 + (c & 1)];
+        fa[slot][j] = pk[off_x + (long long)(c >> 1) * N * 2 + (c & 1)];   // (second touch of the same lines: cached)
       }
     };
 #pragma unroll
@@ -742,7 +747,7 @@ k_big_bwd16(const float* __restrict__ S, const float* __restrict__ x, const floa
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long row = r + 4 * q + j;
-      if (row < r_end) dx[row * 16 + m] = acc_x[j];
+      if (row < r_end) __builtin_nontemporal_store(acc_x[j], dx + row * 16 + m);
     }
   }
   if (wave > 0) {
