@@ -8,6 +8,9 @@
 //             dW_k = T_k^T dpre, db = sum dpre: register-tiled split over row chunks with
 //             per-block partials and a fixed-order final reduce (k_cheb_dw, k_reduce_partials)
 //             -- no atomics, so gradients are bitwise reproducible run to run.
+// Levels of 5120 .. 20480 vertices (BASELINE configs[3]) replace the K-1 propagates by cheb_big.hip's one-launch
+// recurrence over pair-major stack planes, and the 16 -> 16 layer's backward by ONE pass over the T_k(dpre) stack
+// (k_big_bwd16 below: dx and dW / db together).
 // Weights are wave-uniform and read through the scalar cache (s_load) so the inner loops are
 // v_fma with an SGPR operand; activations move as 16-byte vectors.
 #include "common.hpp"
