@@ -1228,7 +1228,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   // (k_big_bwd16); the forward's stack (tx_saved) is not read
   if (dW && dx && K > 1 && K <= 12 && Cin == 16 && Cout == 16 && cheb_big_eligible(lap_t, B, N, Cout, K) &&
       (lap->flags & MVH_CSR_SYMMETRIC) && (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)G | (uintptr_t)dx | (uintptr_t)x) & 15) == 0 &&
-      !dbg().no_dx_tstack && !dbg().no_bwd_fused && rows >= 4096) {
+      !dbg().no_dx_tstack && !dbg().no_bwd_fused && rows >= 4096 && (act != MVH_ACT_RELU || out)) {   // (the mask is read as fp32 rows)
     float* Wt = split;   // [K][Cout][Cin] = W_k^T
     hipLaunchKernelGGL(k_w_transpose, dim3(cdiv(K * Cin * Cout, 256)), dim3(256), 0, st, W, Wt, K, Cin, Cout);
     MVH_LAUNCH_CHECK();
@@ -1366,7 +1366,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   // against 290 + 400 us measured in isolation.
   if (K > 1 && Cin == 16 && Cout == 16 && dx && cheb_big_eligible(lap_t, B, N, Cout, K) &&
       (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)G | (uintptr_t)dx) & 15) == 0 && !dbg().no_dx_tstack &&
-      (size_t)K * Cin * Cout * sizeof(float) <= kSplitScratchBytes) {
+      (size_t)K * Cin * Cout * sizeof(float) <= kSplitScratchBytes && (act != MVH_ACT_RELU || out)) {
     float* Wt = split;   // [K][Cout][Cin] = W_k^T (the split-path scratch is free on this path)
     hipLaunchKernelGGL(k_w_transpose, dim3(cdiv(K * Cin * Cout, 256)), dim3(256), 0, st, W, Wt, K, Cin, Cout);
     MVH_LAUNCH_CHECK();
