@@ -90,8 +90,9 @@ int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
 /* Debug / A-B switches (no reference counterpart).  They live in ONE struct that is filled when the
  * library is loaded from MESHVAE_DEBUG="key=value,..." and is never re-read from the environment;
  * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch,
- * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse, no_big, no_dx_tstack, no_dx_first, no_bwd_fused, no_dw_rows.  mvh_debug_set changes one switch in-process (the tests
- * run both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
+ * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse, no_big, no_dx_tstack,
+ * no_dx_first, no_bwd_fused, no_dw_rows.  mvh_debug_set changes one switch in-process (the tests run
+ * both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
 int mvh_debug_set(const char* key, int32_t value);
 int32_t mvh_debug_get(const char* key);
 

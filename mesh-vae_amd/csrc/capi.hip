@@ -39,9 +39,6 @@ static const DebugKey kDebugKeys[] = {
     {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
     {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
     {"no_bwd_fused", &DebugCfg::no_bwd_fused},   {"no_dw_rows", &DebugCfg::no_dw_rows},
-    {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
-    {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
-    {"no_bwd_fused", &DebugCfg::no_bwd_fused},   {"no_dw_rows", &DebugCfg::no_dw_rows},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {
