@@ -392,6 +392,61 @@ def test_full_model_train_step_wide_kernel_shape(model_5k_npz, model_tiny_npz):
         test_full_model_train_step_matches_reference("5k", model_tiny_npz, model_5k_npz)
 
 
+@pytest.mark.parametrize("which,B", [("tiny", 5), ("5k", 3)])
+def test_full_model_train_step_with_dropout_matches_oracle_under_shared_masks(which, B):
+    """Train mode WITH dropout (p = 0.2) against the oracle: the four nn.Dropout sites of the model (encoder head,
+    classifier, dec_lin, dec_lin_2; cheb_VAE.py:272, 255, 277, 279) take their masks from the same uniforms -- the native
+    step through its drop_u argument, the oracle through a _drop that applies F.dropout's arithmetic (keep where
+    u >= p, scale 1 / (1 - p)) with those uniforms in call order.  Every output and gradient within the 1e-4 bar."""
+    import numpy as np
+    from meshvae_hip.engine import NativeStep
+    from oracle import cheb_oracle as O
+    dev = _dev()
+    topo = "topology_tiny.npz" if which == "tiny" else "topology_5k.npz"
+    net = _build(which, dev, dropout=0.2)
+    net.train()
+    N = net.num_nodes[0]
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, N, 3, generator=g)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2)
+    eps = torch.randn(B, net.z, generator=g)
+    nat = NativeStep(net, B)
+    H, flat = net.num_hidden, nat.u_cols - 3 * net.num_hidden
+    drop_u = torch.rand(B * nat.u_cols, generator=g)
+    loss, corr, recon, (kld, rec, z_), yh = nat.forward_backward(x.to(dev), x.to(dev), y.to(dev), eps=eps.to(dev),
+                                                                 drop_u=drop_u.to(dev))
+    torch.cuda.synchronize()
+    cfg = dict(TINY_CFG if which == "tiny" else CFG_5K, dropout=0.2)
+    ora = O.OracleVAE(cfg, O.Topology(np.load(os.path.join(ROOT, "tests", "golden", topo))),
+                      {k: v.cpu() for k, v in net.state_dict().items()}, requires_grad=True)
+    ora.training = True
+    # the library's layout: four contiguous blocks [B, H] (encoder head) | [B, H] (classifier) | [B, H] (dec_lin) | [B, flat]
+    blocks = [drop_u[0:B * H].reshape(B, H), drop_u[B * H:2 * B * H].reshape(B, H),
+              drop_u[2 * B * H:3 * B * H].reshape(B, H), drop_u[3 * B * H:].reshape(B, flat)]
+    p = 0.2
+
+    def masked_drop(t):
+        u = blocks.pop(0)
+        assert u.shape == t.shape
+        return torch.where(u >= p, t / (1.0 - p), torch.zeros_like(t))
+    ora._drop = masked_drop
+    lo, co, ro, (ko, reco, zo), yo, _, _ = ora.forward(x, x.clone(), y.float(), "train", eps=eps)
+    lo.backward()
+    assert not blocks                                            # all four sites consumed their block, in this order
+    torch.testing.assert_close(z_.cpu(), zo.detach(), rtol=0, atol=FWD_ATOL)
+    torch.testing.assert_close(yh.cpu(), yo.detach(), rtol=0, atol=FWD_ATOL)
+    torch.testing.assert_close(recon.cpu(), ro.detach(), rtol=0, atol=FWD_ATOL)
+    lo_v = float(lo.detach())
+    assert abs(float(loss) - lo_v) <= 2e-6 * abs(lo_v) + 1e-2
+    worst = 0.0
+    got = {k: q.grad.cpu() for k, q in net.named_parameters() if q.grad is not None}
+    for k, gref in ora.grads().items():
+        rel = float((got[k] - gref).norm()) / max(float(gref.norm()), 1e-12)
+        worst = max(worst, rel)
+        assert rel < 1e-4, (k, rel)
+    print(f"[dropout {which}] worst relative gradient error = {worst:.3e}")
+
+
 def test_train_mode_dropout_statistics_and_determinism():
     dev = _dev()
     net = _build("tiny", dev)
