@@ -348,12 +348,17 @@ def test_hires_20k_config_matches_reference(model_20k_npz):
     names = [str(n) for n in npz["train/grad_names"]]
     got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
     assert sorted(got) == sorted(names)
+    worst = 0.0
     for k in names:
+        # the same 1e-4 relative bar as the tiny / 5k models (measured on MI355X: every tensor within 1.8e-5, on its
+        # norm and on the stored head of 1024 entries; K = 10 recurrences through six levels, fp32 sums of 40 k rows)
         gn = float(npz[f"train/gnorm/{k}"])
-        assert abs(float(got[k].double().norm()) - gn) <= 5e-4 * gn + 1e-7, (k, float(got[k].double().norm()), gn)
-        # per-element: 1e-3 of the tensor's RMS entry (K = 10 recurrences through six levels; fp32 sums of 40 k rows)
-        torch.testing.assert_close(got[k].reshape(-1)[:1024].cpu(), _t(npz[f"train/grad_head/{k}"]), rtol=2e-3,
-                                   atol=1e-3 * max(gn / max(got[k].numel() ** 0.5, 1.0), 1e-3), msg=k)
+        assert abs(float(got[k].double().norm()) - gn) <= 1e-4 * gn + 1e-7, (k, float(got[k].double().norm()), gn)
+        want = _t(npz[f"train/grad_head/{k}"])
+        rel = float((got[k].reshape(-1)[:1024].cpu() - want).norm()) / max(float(want.norm()), 1e-30)
+        worst = max(worst, rel)
+        assert rel < 1e-4, (k, rel)
+    print(f"[20k] worst relative gradient error (head of 1024 entries) = {worst:.3e}")
 
 
 @pytest.mark.parametrize("which", ["tiny", "5k"])
