@@ -83,6 +83,12 @@ typedef struct mvh_csr {
 #define MVH_CSR_SELECTION 4
 #define MVH_CSR_ELL_OVERFLOW 8
 
+/* ABI version of this header: 100 * round + revision.  It changes whenever a struct layout or an argument list
+ * changes incompatibly; a binding must compare mvh_version() with the MVH_ABI_VERSION it was written against before
+ * any other call (the Python binding does, meshvae_hip/__init__.py).  History: 100 = round 1; 300 = `storage`
+ * inserted into mvh_vae_desc_t, skip_lo / skip_hi appended to mvh_adam_step / mvh_adam_step_counted (round 2,
+ * shipped unversioned), version check introduced (round 3). */
+#define MVH_ABI_VERSION 300
 int mvh_version(void);
 const char* mvh_last_error(void);
 /* Device properties of the current HIP device (arch string e.g. "gfx950"). */

@@ -88,7 +88,7 @@ extern "C" int32_t mvh_debug_get(const char* key) {
   return f ? dbg().*f : -1;
 }
 
-extern "C" int mvh_version(void) { return 100; }
+extern "C" int mvh_version(void) { return MVH_ABI_VERSION; }
 
 extern "C" const char* mvh_last_error(void) { return last_error_buf(); }
 

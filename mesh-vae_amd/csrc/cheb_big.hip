@@ -250,11 +250,8 @@ static int big_launch(hipStream_t st, const mvh_csr_t* lap, const float* in, flo
   const size_t lds = (size_t)(N + 1) * 8;
   const int grid = ((B + 7) / 8) * 8 * ((C + 1) / 2);
   auto go = [&](auto kern) -> int {
-    static size_t attr = 0;   // (one per instantiation of this lambda, i.e. per kernel)
-    if (lds > attr) {
-      MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = lds;
-    }
+    static LdsAttr attr;   // (one per instantiation of this lambda, i.e. per kernel; per device, thread-safe)
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBigThreads), lds, st, a);
     return MVH_OK;
   };

@@ -1228,7 +1228,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   // (k_big_bwd16); the forward's stack (tx_saved) is not read
   if (dW && dx && K > 1 && K <= 12 && Cin == 16 && Cout == 16 && cheb_big_eligible(lap_t, B, N, Cout, K) &&
       (lap->flags & MVH_CSR_SYMMETRIC) && (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)G | (uintptr_t)dx | (uintptr_t)x) & 15) == 0 &&
-      !dbg().no_dx_tstack && !dbg().no_bwd_fused && rows >= 4096 && (act != MVH_ACT_RELU || out)) {   // (the mask is read as fp32 rows)
+      !dbg().no_dx_tstack && !dbg().no_bwd_fused && rows >= 4096 && (act != MVH_ACT_RELU || out) && !bf) {   // (the mask and every
+    // operand are read as fp32 rows: bf16 tensors must reach the MVH_ERR_UNSUPPORTED check below, never this kernel)
     float* Wt = split;   // [K][Cout][Cin] = W_k^T
     hipLaunchKernelGGL(k_w_transpose, dim3(cdiv(K * Cin * Cout, 256)), dim3(256), 0, st, W, Wt, K, Cin, Cout);
     MVH_LAUNCH_CHECK();

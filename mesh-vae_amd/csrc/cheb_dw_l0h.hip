@@ -233,12 +233,8 @@ int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   const int NW = kDwhThreads / 64;
   DwL0hDims d{B, N, K, N, db ? 1 : 0, out_bits ? 1 : 0};
   const size_t lds = (size_t)kDwhSlots * 32;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cheb_dw_l0h), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_set = true;
-  }
+  static LdsAttr attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(k_cheb_dw_l0h), lds)) return rc;
   const int grid = ((B + 7) / 8) * 8 * 4;
   hipLaunchKernelGGL(k_cheb_dw_l0h, dim3(grid), dim3(kDwhThreads), lds, st, reinterpret_cast<const uint16_t*>(x),
                      reinterpret_cast<const uint16_t*>(dout), out_bits, lap->rowinfo, lap->ell, part, d);

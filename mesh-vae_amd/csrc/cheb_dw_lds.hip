@@ -576,12 +576,8 @@ static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const 
                          const mvh_csr_t* lap, float* part, const DwDims& d, int threads, const int32_t* map) {
   auto kern = k_cheb_dw_lds<CQ, VPT, TCT, PW>;
   const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
-  static size_t attr_bytes = 0;
-  if (lds > attr_bytes) {
-    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_bytes = lds;
-  }
+  static LdsAttr attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
   const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, d);

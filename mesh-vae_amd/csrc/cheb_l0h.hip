@@ -269,15 +269,12 @@ int try_cheb_l0h(hipStream_t st, const mvh_csr_t* lap, const float* in, const ui
     wh = (const uint32_t*)wpack;
   }
   const size_t lds = (size_t)kL0hSlots * 32;
-  static bool attr_set[2] = {false, false};
+  static LdsAttr attr_set[2];
   const int grid = ((B + 7) / 8) * 8 * 4;
 #define MVH_L0H(BW)                                                                                                        \
   do {                                                                                                                     \
     auto kern = k_cheb_l0h<BW>;                                                                                            \
-    if (!attr_set[BW ? 1 : 0]) {                                                                                           \
-      MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      attr_set[BW ? 1 : 0] = true;                                                                                         \
-    }                                                                                                                      \
+    if (int rc = attr_set[BW ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kL0hThreads), lds, st, reinterpret_cast<const uint16_t*>(in), mask_bits, wh, \
                        bias, out, o.bits_out, lap->rowinfo, lap->ell, pt_rowptr, pt_col, pt_val, pooled, d);               \
   } while (0)

@@ -587,12 +587,8 @@ template <int CQ, int VPT, int TCT, int PW, bool BWD>
 static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   auto kern = k_cheb_lds<CQ, VPT, TCT, PW, BWD>;
   const size_t lds = (size_t)VPT * threads * (TCT == 0 ? 32 : 16 + PW * 4);
-  static size_t attr_bytes = 0;
-  if (lds > attr_bytes) {
-    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_bytes = lds;
-  }
+  static LdsAttr attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,

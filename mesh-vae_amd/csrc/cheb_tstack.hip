@@ -228,11 +228,8 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
   TstackDims d{B, N, K, Cin, pool->n_rows};
   const size_t lds = (size_t)5120 * (16 + 4 * 4);
   auto kern = k_cheb_tstack<10, 512, 4>;  // 256 VGPRs per lane: the 1024 x 5 shape spilled 86 of its 128
-  static bool attr = false;
-  if (!attr) {
-    MVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static LdsAttr attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, st, x, lap->rowinfo, lap->ell, stack, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -36,6 +37,26 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int check_csr(const mvh_csr_t* op, const char* what);
+
+// "The dynamic-LDS limit of this kernel is already >= bytes on the current device": one static instance per launch
+// site (= per kernel instantiation), keyed by device and lock-free, so that launches from several host threads (the
+// eager n_micro > 1 mode) and on several devices of one process are safe.  hipFuncSetAttribute itself is idempotent.
+struct LdsAttr {
+  std::atomic<size_t> have[16];
+  LdsAttr() { for (auto& h : have) h.store(0, std::memory_order_relaxed); }
+  int ensure(const void* kern, size_t bytes) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev >= 0 && have[dev].load(std::memory_order_acquire) >= bytes) return MVH_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(MVH_ERR_HIP, "hipFuncSetAttribute(dynamic LDS %zu) failed: %s", bytes, hipGetErrorString(e));
+    if (dev >= 0) {
+      size_t cur = have[dev].load(std::memory_order_relaxed);
+      while (cur < bytes && !have[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+    return MVH_OK;
+  }
+};
 
 // Debug / A-B switches of the whole library: ONE struct, filled once when the library is loaded from
 // MESHVAE_DEBUG="key=value,key=value" (keys = the member names) and changed afterwards only through

@@ -49,6 +49,7 @@ class VaeDesc(ctypes.Structure):
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
 STORAGE_F32, STORAGE_BF16 = 0, 1
+ABI_VERSION = 300   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 
@@ -110,6 +111,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        if handle.mvh_version() != ABI_VERSION:
+            raise MeshVaeHipError(f"libmeshvae_hip.so speaks ABI {handle.mvh_version()}, this binding {ABI_VERSION} (stale build?)")
         if handle.mvh_sizeof_csr() != ctypes.sizeof(CsrStruct) or handle.mvh_sizeof_vae_desc() != ctypes.sizeof(VaeDesc):
             raise MeshVaeHipError("ctypes struct layout does not match libmeshvae_hip.so (stale build?)")
         _lib = handle

@@ -217,3 +217,40 @@ def test_bf16_refuses_levels_without_lds_kernels():
     y = torch.nn.functional.one_hot(torch.arange(1) % 2, 2).to(dev)
     with pytest.raises(meshvae_hip.MeshVaeHipError, match="bf16 storage"):
         step.forward_backward(x, x, y, None, None, backward=False)
+
+
+def test_bf16_public_conv_entries_refuse_streaming_levels():
+    """The public bf16 conv entries on topology_20k's level 0 (19 992 vertices: no LDS-resident kernel) -- forward,
+    backward with a ReLU mask, and backward with act = NONE and both gradients asked for, which is the argument pattern
+    of the fused two-gradient fp32 kernel (k_big_bwd16: it would read the 2-byte buffers as fp32): all three must
+    return MVH_ERR_UNSUPPORTED and touch nothing (the canaries behind the bf16-sized buffers stay)."""
+    from meshvae_hip import lib
+    dev = _dev()
+    npz = np.load(os.path.join(ROOT, "tests", "golden", "topology_20k.npz"))
+    lap, ei, nrm, N = _laplacian(npz, 0, dev)
+    B, C, K = 1, 16, 6
+    L = lib()
+    g = torch.Generator().manual_seed(2)
+    pad = 4096                                            # canary elements behind every bf16-sized tensor
+    def bf(n):
+        t = torch.full((n + pad,), 7.0, dtype=torch.bfloat16, device=dev)
+        t[:n] = torch.randn(n, generator=g).to(torch.bfloat16).to(dev)
+        return t
+    x, dout, out, dx = bf(B * N * C), bf(B * N * C), bf(B * N * C), bf(B * N * C)
+    W = (torch.randn(K, C, C, generator=g) * 0.1).to(dev)
+    dW, db = torch.zeros_like(W), torch.zeros(C, device=dev)
+    signs = torch.zeros(B, N, C // 4, dtype=torch.uint8, device=dev)
+    wsb = max(L.mvh_cheb_conv_ws_bytes(B, N, C, C, K), L.mvh_cheb_conv_bwd_ws_bytes(B, N, C, C, K))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: t.data_ptr()  # noqa: E731
+    rc = L.mvh_cheb_conv_fwd_bf16(st, lap.fwd.ref, p(x), p(W), None, p(out), p(signs), B, N, C, C, K, 1, p(ws), wsb)
+    assert rc != 0 and b"bf16 storage" in L.mvh_last_error()
+    for act, sg in ((1, p(signs)), (0, None)):
+        rc = L.mvh_cheb_conv_bwd_bf16(st, lap.fwd.ref, lap.bwd.ref, p(x), p(W), sg, p(dout), p(dx), p(dW), p(db), B, N, C, C, K,
+                                      act, p(ws), wsb)
+        assert rc != 0 and b"bf16 storage" in L.mvh_last_error(), (act, rc, L.mvh_last_error())
+    torch.cuda.synchronize()
+    for t in (x, dout, out, dx):
+        assert bool((t[-pad:].float() == 7.0).all())
+    assert float(dW.abs().max()) == 0.0 and float(db.abs().max()) == 0.0

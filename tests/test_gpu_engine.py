@@ -217,6 +217,39 @@ def test_trainstep_private_noise_generators():
     assert runs[0] == runs[1] and runs[0] != runs[2]
 
 
+def test_trainstep_graph_with_private_noise_replays_fresh_masks():
+    """hipGraph replay with the step's private generators (noise_seed): the dropout uniforms are drawn OUTSIDE the
+    graph into static buffers before every replay, so two replays use different masks (a generator consumed inside the
+    capture would bake one offset into the graph) and the loss sequence equals the eager run with the same seed."""
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    B = 4
+    x = torch.randn(B, 162, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    seqs, masks = {}, {}
+    for mode in ("eager", "graph"):
+        net = _net(dev, dropout=0.2).train()
+        step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=(mode == "graph"), noise_seed=3)
+        step.load(x, x, y)
+        init = step.flat.param.clone()
+        if step.use_graph:
+            step.capture(warmup=2)                 # consumes noise and touches params / Adam state: reset both
+        from meshvae_hip.engine import rank_generators
+        step.host_gen, step.dev_gen = rank_generators(3, 0, dev)
+        step.flat.param.copy_(init)
+        step.opt.exp_avg.zero_(), step.opt.exp_avg_sq.zero_(), step.opt.step_count.zero_()
+        step.opt._host_step = None
+        ls, us = [], []
+        for _ in range(4):
+            ls.append(float(step.step()[0]))
+            us.append(step._u_bufs[0].clone())
+        seqs[mode], masks[mode] = ls, us
+    assert not torch.equal(masks["graph"][0], masks["graph"][1])            # every replay has its own uniforms
+    assert all(torch.equal(a, b) for a, b in zip(masks["graph"], masks["eager"]))
+    torch.testing.assert_close(torch.tensor(seqs["graph"]), torch.tensor(seqs["eager"]), rtol=1e-6, atol=1e-3)
+    assert len(set(seqs["graph"])) == 4
+
+
 def test_flat_grads_equal_plain_autograd():
     from meshvae_hip.engine import FlatParams
     dev = torch.device("cuda:0")
@@ -394,7 +427,7 @@ def test_dense_gradients_are_final_at_the_library_event():
     snap = torch.empty_like(flat.grad[split:])
     for _ in range(3):
         flat.grad.fill_(float("nan"))
-        step._draw_eps()
+        step._draw_noise()
         step._fwd_bwd()
         meshvae_hip.check(meshvae_hip.lib().mvh_vae_wait_dense_grads(comm.cuda_stream))
         with torch.cuda.stream(comm):
