@@ -326,6 +326,14 @@ size_t mvh_sizeof_vae_desc(void);
 size_t mvh_sizeof_csr(void);
 size_t mvh_vae_step_ws_bytes(const mvh_vae_desc_t* desc, int32_t B);
 int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc);
+/* Test aid (no reference counterpart): where one activation / activation-gradient tensor of the step lives in `ws`,
+ * so that parity tests can hold the INTERMEDIATE tensors of mvh_vae_forward / mvh_vae_backward against the oracle's,
+ * not only the module outputs.  name: "encA" | "encP" | "decU" | "decC" (conv output / pooled output of encoder stage
+ * `index`; un-pooled input / conv output of decoder stage `index`), their gradients "g_encA" | "g_encP" | "g_decU" |
+ * "g_decC", and (index ignored) "h" "zy" "d1" "d2" "g_h" "g_zy" "g_d1" "g_d2" "g_recon".  Returns the byte offset and
+ * stores the element count, or -1 for an unknown name / index.  Which of these a given configuration really writes
+ * (fused pooling keeps some tensors in LDS only) is private to the library: the tests state what they read. */
+int64_t mvh_vae_ws_offset(const mvh_vae_desc_t* desc, int32_t B, const char* name, int32_t index, int64_t* n_elems);
 int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float* const* params,
                     const float* x, const float* y, const void* x_gt, int32_t gt_f64, const float* eps,
                     const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,

@@ -196,6 +196,36 @@ extern "C" size_t mvh_vae_step_ws_bytes(const mvh_vae_desc_t* desc, int32_t B) {
   return p.total;
 }
 
+extern "C" int64_t mvh_vae_ws_offset(const mvh_vae_desc_t* desc, int32_t B, const char* name, int32_t index, int64_t* n_elems) {
+  StepPlan p;
+  if (!desc || !name || build_plan(desc, B, p)) return -1;
+  const int n = p.n;
+  auto lvl_of = [&](int i) { return n - i - 1; };
+  struct V { const char* nm; const std::vector<size_t>* v; int kind; };   // kind: 0 encA 1 encP 2 decU 3 decC
+  const V vs[] = {{"encA", &p.encA, 0}, {"g_encA", &p.g_encA, 0}, {"encP", &p.encP, 1}, {"g_encP", &p.g_encP, 1},
+                  {"decU", &p.decU, 2}, {"g_decU", &p.g_decU, 2}, {"decC", &p.decC, 3}, {"g_decC", &p.g_decC, 3}};
+  for (const V& v : vs)
+    if (!strcmp(name, v.nm)) {
+      if (index < 0 || index >= n) return -1;
+      const int i = index;
+      const int64_t cnt = v.kind == 0 ? (int64_t)B * p.Nn[i] * p.f[i + 1] : v.kind == 1 ? (int64_t)B * p.Nn[i + 1] * p.f[i + 1]
+                          : v.kind == 2 ? (int64_t)B * p.Nn[lvl_of(i)] * p.f[n + 1 - i] : (int64_t)B * p.Nn[lvl_of(i)] * p.f[n - i];
+      if (n_elems) *n_elems = cnt;
+      return (int64_t)(*v.v)[i];
+    }
+  struct S { const char* nm; size_t off; int64_t cnt; };
+  const S ss[] = {{"h", p.h, (int64_t)B * p.H}, {"g_h", p.g_h, (int64_t)B * p.H}, {"zy", p.zy, (int64_t)B * (p.C + p.Z)},
+                  {"g_zy", p.g_zy, (int64_t)B * (p.C + p.Z)}, {"d1", p.d1, (int64_t)B * p.H}, {"g_d1", p.g_d1, (int64_t)B * p.H},
+                  {"d2", p.d2, (int64_t)B * p.flat}, {"g_d2", p.g_d2, (int64_t)B * p.flat},
+                  {"g_recon", p.g_recon, (int64_t)B * p.Nn[0] * p.F0}};
+  for (const S& e : ss)
+    if (!strcmp(name, e.nm)) {
+      if (n_elems) *n_elems = e.cnt;
+      return (int64_t)e.off;
+    }
+  return -1;
+}
+
 extern "C" int32_t mvh_vae_param_count(const mvh_vae_desc_t* desc) {
   if (!desc) return 0;
   ParamIdx ix{desc->n_layers};

@@ -92,6 +92,7 @@ SIGNATURES = {
     "mvh_sizeof_csr": (_Z, []),
     "mvh_vae_step_ws_bytes": (_Z, [ctypes.POINTER(VaeDesc), _I]),
     "mvh_vae_param_count": (ctypes.c_int32, [ctypes.POINTER(VaeDesc)]),
+    "mvh_vae_ws_offset": (ctypes.c_int64, [ctypes.POINTER(VaeDesc), _I, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_int64)]),
     "mvh_vae_forward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
     "mvh_vae_backward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z, _P]),
     "mvh_vae_backward_prefetch": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _I, _P, _Z, _P]),

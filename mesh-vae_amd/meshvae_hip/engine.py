@@ -580,6 +580,15 @@ class NativeStep:
                                        recon.data_ptr(), self.ws.data_ptr(), self.ws_bytes))
         return recon
 
+    def ws_tensor(self, name, index=0):
+        """Test aid: a flat fp32 view of one activation / gradient tensor of the last step inside the workspace
+        (mvh_vae_ws_offset; fp32 storage only)."""
+        cnt = ctypes.c_int64(0)
+        off = lib().mvh_vae_ws_offset(ctypes.byref(self.desc), self.B, name.encode(), index, ctypes.byref(cnt))
+        if off < 0:
+            raise KeyError((name, index))
+        return self.ws[off:off + 4 * cnt.value].view(torch.float32)
+
     def _refresh_pointers(self):
         for i, p in enumerate(self.params):
             self._P[i], self._G[i] = p.data_ptr(), self.grads[i].data_ptr()

@@ -68,12 +68,25 @@ def _native(net, B, x, y, eps, drop_u, storage="f32", gt64=False):
     return nat, out
 
 
-def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat):
+def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat, dtype=torch.float32, pins=None):
+    """dtype = float32: the reference's arithmetic (the parity bar).  float64: the exact answer, used only to print how
+    far this library and the reference's own fp32 rounding each are from it.
+    Records the pre-activation of every ReLU site (result["pre"][site]); pins = {site: bool mask} replaces the ReLU
+    decision of that site by the given mask (see _relu_ties)."""
     from oracle import cheb_oracle as O
     B = x.shape[0]
-    ora = O.OracleVAE(dict(cfg, dropout=P_DROP), O.Topology(np.load(os.path.join(ROOT, "tests", "golden", topo_name))),
-                      {k: v.cpu() for k, v in net.state_dict().items()}, requires_grad=True)
+
+    class Recording(O.OracleVAE):
+        def _relu(self, site, t):
+            self.pre[site] = t.detach()
+            if pins and site in pins:
+                return t * pins[site].to(t.dtype)
+            return torch.relu(t)
+    ora = Recording(dict(cfg, dropout=P_DROP), O.Topology(np.load(os.path.join(ROOT, "tests", "golden", topo_name))),
+                    {k: v.cpu() for k, v in net.state_dict().items()}, requires_grad=True, dtype=dtype)
+    ora.pre = {}
     ora.training = True
+    x, eps = x.to(dtype), eps.to(dtype)
     blocks = _drop_blocks(drop_u, B, H, flat)
 
     def masked_drop(t):          # F.dropout's arithmetic on the shared uniforms, in the model's call order
@@ -81,14 +94,48 @@ def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat):
         assert u.shape == t.shape
         return torch.where(u >= P_DROP, t / (1.0 - P_DROP), torch.zeros_like(t))
     ora._drop = masked_drop
-    lo, co, ro, (ko, reco, zo), yo, _, _ = ora.forward(x, x.clone(), y.float(), "train", eps=eps)
+    lo, co, ro, (ko, reco, zo), yo, _, _ = ora.forward(x, x.clone(), y.to(dtype), "train", eps=eps)
     lo.backward()
     assert not blocks
     return dict(loss=float(lo.detach()), correct=int(co), recon=ro.detach(), kld=ko.detach(), rec=reco.detach(),
-                z=zo.detach(), y_hat=yo.detach(), grads=ora.grads())
+                z=zo.detach(), y_hat=yo.detach(), grads=ora.grads(), pre=ora.pre)
 
 
-def _compare_with_oracle(got, want, tag, grad_bar=1e-4):
+def _relu_ties(nat, net, want, drop_u, tag):
+    """Two fp32 evaluation orders disagree on the sign of a pre-activation that is zero to rounding (measured: B = 64
+    meshes of the 5k model have 15 M ReLU inputs of magnitude O(1); about one per step lies within 1e-7 of zero, e.g.
+    2.5e-8 in float64), and the ReLU derivative is discontinuous there, so ONE such element moves every upstream
+    gradient by 1e-5 .. 1e-4 relative.  That is not an error of either side.  This helper compares the ReLU decisions
+    of the native step (the stored post-activation tensors of its workspace) with the oracle's at every conv site and
+    dense site, REQUIRES every disagreement to sit at |pre-activation| <= 5e-6 of the site's largest -- 20 x tighter than the
+    forward bar; K = 10 recurrences at the 20k level carry 1e-6 of fp32 noise -- (anything else
+    is a real sign error and fails), and returns pins = {site: this library's mask} for the sites that have ties."""
+    n, B = net.n_layers, nat.B
+    H, flat = net.num_hidden, net.dec_lin_2.out_features
+    blocks = _drop_blocks(drop_u, B, H, flat)
+    sites = [(f"cheb.{i}", ("encA", i), None) for i in range(n)] + [(f"cheb_dec.{i}", ("decC", i), None) for i in range(n)]
+    sites += [("enc_lin", ("h", 0), blocks[0]), ("dec_lin", ("d1", 0), blocks[2]), ("dec_lin_2", ("d2", 0), blocks[3])]
+    pins, notes = {}, []
+    for site, (name, idx), u in sites:
+        pre = want["pre"][site]
+        ours = nat.ws_tensor(name, idx).cpu().reshape(pre.shape) > 0
+        theirs = pre > 0
+        diff = ours != theirs
+        if u is not None:                       # a dropped element says nothing about the ReLU decision
+            diff &= (u >= P_DROP)
+        if not bool(diff.any()):
+            continue
+        scale = float(pre.abs().max())
+        worst = float(pre[diff].abs().max())
+        assert worst <= 5e-6 * scale, (site, "ReLU sign differs at a pre-activation that is NOT a tie", worst, scale)
+        pins[site] = torch.where(diff, ours, theirs)
+        notes.append(f"{site}: {int(diff.sum())} tie(s), |pre| <= {worst:.1e} of max {scale:.1e}")
+    if notes:
+        print(f"[{tag}] ReLU ties pinned to this library's decision: " + "; ".join(notes))
+    return pins
+
+
+def _compare_with_oracle(got, want, tag, grad_bar=1e-4, truth=None):
     torch.testing.assert_close(got["z"], want["z"], rtol=0, atol=FWD_ATOL)
     torch.testing.assert_close(got["y_hat"], want["y_hat"], rtol=0, atol=FWD_ATOL)
     torch.testing.assert_close(got["recon"], want["recon"], rtol=0, atol=FWD_ATOL)       # ALL meshes
@@ -98,12 +145,22 @@ def _compare_with_oracle(got, want, tag, grad_bar=1e-4):
     assert abs(got["loss"] - want["loss"]) <= 2e-6 * abs(want["loss"]) + 1e-2
     per_mesh = (got["recon"] - want["recon"]).abs().flatten(1).max(dim=1).values
     worst, worst_k = 0.0, None
-    assert sorted(got["grads"]) == sorted(want["grads"])
+    assert set(want["grads"]) <= set(got["grads"])        # (dec_lin_1 has no gradient in the reference: its span stays zero)
+    assert all(float(got["grads"][k].abs().max()) == 0.0 for k in set(got["grads"]) - set(want["grads"]))
+    table, bad = [], []
     for k, gref in want["grads"].items():
         rel = float((got["grads"][k] - gref).norm()) / max(float(gref.norm()), 1e-12)
+        row = f"{k}={rel:.1e}"
+        if truth is not None:        # distance of this library / of the reference's fp32 arithmetic from the exact answer
+            t = truth["grads"][k]
+            row += f"({float((got['grads'][k].double() - t).norm() / t.norm()):.1e}/{float((gref.double() - t).norm() / t.norm()):.1e})"
+        table.append(row)
         if rel > worst:
             worst, worst_k = rel, k
-        assert rel < grad_bar, (k, rel)
+        if not rel < grad_bar:
+            bad.append((k, rel))
+    print(f"[{tag}] gradient rel error vs oracle" + (" (vs fp64 truth: this library / reference fp32)" if truth else "") + ": " + " ".join(table))
+    assert not bad, bad
     print(f"[{tag}] max|recon - oracle| per mesh: worst {float(per_mesh.max()):.2e} (mesh {int(per_mesh.argmax())}); "
           f"worst relative gradient error {worst:.2e} ({worst_k})")
 
@@ -119,7 +176,11 @@ def test_b64_fp32_step_matches_oracle_on_all_meshes():
     nat, got = _native(net, B, x, y, eps, drop_u)
     assert nat.u_cols == 3 * H + flat
     want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat)
-    _compare_with_oracle(got, want, "b64 fp32 5k")
+    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 5k")
+    if pins:
+        want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
+    truth = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat, dtype=torch.float64, pins=pins)
+    _compare_with_oracle(got, want, "b64 fp32 5k", truth=truth)
 
 
 def test_b64_bf16_step_against_fp32_step_and_oracle():
@@ -142,6 +203,9 @@ def test_b64_bf16_step_against_fp32_step_and_oracle():
     assert abs(b16["loss"] - f32["loss"]) < 1e-5 * abs(f32["loss"])
     worst, worst_k = 0.0, None
     for k, gref in f32["grads"].items():
+        if float(gref.abs().max()) == 0.0:          # dec_lin_1: no gradient in the reference, the span stays zero
+            assert float(b16["grads"][k].abs().max()) == 0.0
+            continue
         rel = float((b16["grads"][k] - gref).norm()) / max(float(gref.norm()), 1e-12)
         cos = float(torch.nn.functional.cosine_similarity(b16["grads"][k].reshape(1, -1).double(), gref.reshape(1, -1).double()))
         assert cos > 0.99, (k, cos)
@@ -160,9 +224,13 @@ def test_b64_hires20k_step_matches_oracle_on_all_meshes():
     x, y, eps, g = _inputs(net, B, seed=32)
     H, flat = net.num_hidden, net.dec_lin_2.out_features
     drop_u = torch.rand(B * (3 * H + flat), generator=g)
-    _, got = _native(net, B, x, y, eps, drop_u)
+    nat, got = _native(net, B, x, y, eps, drop_u)
     want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat)
-    _compare_with_oracle(got, want, "b64 fp32 20k")
+    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k")
+    if pins:
+        want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
+    truth = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, dtype=torch.float64, pins=pins)
+    _compare_with_oracle(got, want, "b64 fp32 20k", truth=truth)
 
 
 @pytest.mark.parametrize("which", ["5k", "20k"])
