@@ -39,6 +39,8 @@ static const DebugKey kDebugKeys[] = {
     {"no_head_fuse", &DebugCfg::no_head_fuse},   {"no_big", &DebugCfg::no_big},
     {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
     {"no_bwd_fused", &DebugCfg::no_bwd_fused},   {"no_dw_rows", &DebugCfg::no_dw_rows},
+    {"keep_enc_out", &DebugCfg::keep_enc_out},   {"dw_lane2", &DebugCfg::dw_lane2},
+    {"tstack_tall", &DebugCfg::tstack_tall},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

@@ -1048,6 +1048,7 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     fo.in_bf16 = io.x; fo.out_bf16 = io.out; fo.pooled_bf16 = io.pooled; fo.prepacked_h = io.wh;
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
     fo.bits_out = bits_out;
+    fo.out_dead = io.out_dead && fo.pool_inv != nullptr && bits_out != nullptr;
     bool pooled_in_kernel = fo.pool_inv != nullptr;
     if (pool && pooled && !fo.pool_inv) {  // general operator (the decoder's upsampling): pooled from LDS in the epilogue
       fo.out_pool_t = pool; fo.pooled = pooled;

@@ -51,6 +51,7 @@ struct LdsConvArgs {
   const float* pt_val;
   int pt_rows;
   int in_bf16, out_bf16, pooled_bf16;  // storage type of in / out / pooled: bf16 instead of fp32 (bf16.hpp)
+  int out_dead;                        // forward + pool_inv: only the selected rows (and their sign bytes) are stored
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 // PW = ELL words per vertex in LDS (4 -> up to 8 neighbours, 8 -> up to 16)
 struct LdsConvDims {
   int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows, ovf;
-  int in_bf16, out_bf16, pooled_bf16;
+  int in_bf16, out_bf16, pooled_bf16, out_dead;
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -97,6 +98,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   const int mesh = (jj / NS) * 8 + xcd, s0 = (jj % NS) * 4;
   if (mesh >= a.B) return;  // uniform per block, before any barrier
   const int tid = threadIdx.x, N = a.N;
+  MVH_STAMPX(0);
 
   if constexpr (!kDB) {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
@@ -108,6 +110,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     }
   }
   uint4 ids[kDB ? VPT : 1][PW / 4];
+  MVH_STAMPX(1);
 
   // ---- own vertices: -2/deg and the input rows scaled by s = deg^-1/2 (0 for slots past N)
   float ka2[VPT];
@@ -266,6 +269,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     }
   }
 
+  MVH_STAMPX(2);
   // acc[vi] += xs[vi][:] . W_k[:, slab]   (weights are wave-uniform: scalar loads, SGPR operands)
   const bool slab_full = s0 + 4 <= a.CO;
   const float* __restrict__ wslab = p_W + (long long)(s0 >> 2) * a.K * CQ * 4;
@@ -372,7 +376,9 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       if constexpr (kDB) slabB[tid + vi * THREADS] = make_float4(0.f, 0.f, 0.f, 0.f);  // u_K = 0
       R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);  // u_K = 0
     }
+    MVH_STAMPX(3);
     __syncthreads();  // slab (+ ELL image) staged
+    MVH_STAMPX(4);
     // Waves w and w + NW/2 share a SIMD: the second half gathers first and contracts after, so at any
     // time one partner is on the VALU (weight FMAs) while the other waits on LDS gathers
     // (MI355X_MICROARCH "two waves per SIMD": split roles by wave number >= NW/2, not by parity).
@@ -414,7 +420,9 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           contract(R, k);
           gather_axpy(R, 1.0f, slab);
         }
+        MVH_STAMPX(5 + 3 * (a.K - 2 - k));
         __syncthreads();  // every gather of u_{k+1} is done
+        MVH_STAMPX(6 + 3 * (a.K - 2 - k));
 #pragma unroll
         for (int vi = 0; vi < VPT; ++vi) {
           const int v = tid + vi * THREADS;
@@ -423,6 +431,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
           R[vi] = old;
         }
         __syncthreads();
+        MVH_STAMPX(7 + 3 * (a.K - 2 - k));
       }
 #pragma unroll
       for (int vi = 0; vi < VPT; ++vi) R[vi] = make_float4(-R[vi].x, -R[vi].y, -R[vi].z, -R[vi].w);
@@ -438,6 +447,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     contract(R, 0);
   }
 
+  MVH_STAMPX(26);
   // ---- epilogue: unscale (1/s = sqrt(deg)), bias, activation, one store per vertex
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   if (!BWD && p_bias) {
@@ -471,26 +481,28 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
     }
-    if (!BWD && p_bits_out)  // CO % 4 == 0 (checked on the host): one sign byte per (vertex, slab)
+    const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
+    const bool dead = a.out_dead && pr < 0;          // a row nobody reads: neither its values nor its sign byte
+    if (!BWD && p_bits_out && !dead)  // CO % 4 == 0 (checked on the host): one sign byte per (vertex, slab)
       p_bits_out[((long long)mesh * a.out_bs + v) * (a.CO >> 2) + (s0 >> 2)] =
           (uint8_t)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
     if (!BWD && scatter) stage[v] = make_float4(o[0], o[1], o[2], o[3]);
     float* dst = outb + (long long)v * a.CO + s0;
-    const int pr = p_pool_inv ? p_pool_inv[v] : -1;  // fused one-hot downsampling (nn/pool.py D)
     float* pdst = p_pooled + ((long long)mesh * a.pooled_bs + max(pr, 0)) * a.CO + s0;
     if (vec_store) {  // (bf16 storage: the host guarantees CO % 4 == 0, i.e. this branch)
-      store4_any(p_out, ((long long)mesh * a.out_bs + v) * a.CO + s0, a.out_bf16 != 0, o[0], o[1], o[2], o[3]);
+      if (!a.out_dead) store4_any(p_out, ((long long)mesh * a.out_bs + v) * a.CO + s0, a.out_bf16 != 0, o[0], o[1], o[2], o[3]);
       if (pr >= 0)
         store4_any(p_pooled, ((long long)mesh * a.pooled_bs + pr) * a.CO + s0, a.pooled_bf16 != 0, o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (s0 + j < a.CO) {
-          dst[j] = o[j];
+          if (!a.out_dead) dst[j] = o[j];
           if (pr >= 0) pdst[j] = o[j];
         }
     }
   }
+  MVH_STAMPX(27);
   if (scatter) {
     __syncthreads();
     for (int c = tid; c < a.pt_rows; c += THREADS) {
@@ -523,7 +535,15 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
       else store4_any(p_pooled, ((long long)mesh * a.pooled_bs + c) * a.CO + s0, a.pooled_bf16 != 0, acc.x, acc.y, acc.z, acc.w);
     }
   }
+#ifdef MVH_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic build: the stores have left the wave)
+#endif
+  MVH_STAMPX(28);
 }
+
+#ifdef MVH_STAMP
+MVH_STAMP_READER(mvh_debug_read_stamps_lds)
+#endif
 
 // Wp[slab][k][c][j] = W[k][c][4 slab + j] (forward) or W[k][4 slab + j][c] (backward, W^T);
 // entries past the last output channel are zero.  K*Cin*Cout <= ~10k floats: one tiny launch.
@@ -592,7 +612,7 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
-                a.mask_bits, a.pt_rows, a.ovf, a.in_bf16, a.out_bf16, a.pooled_bf16};
+                a.mask_bits, a.pt_rows, a.ovf, a.in_bf16, a.out_bf16, a.pooled_bf16, a.out_dead};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
                      a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, a.col, d);
   MVH_LAUNCH_CHECK();
@@ -657,6 +677,7 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   LdsConvArgs a;
   a.mask_bits = 0; a.bits_out = nullptr;
   a.in_bf16 = o.in_bf16 ? 1 : 0; a.out_bf16 = o.out_bf16 ? 1 : 0; a.pooled_bf16 = o.pooled_bf16 ? 1 : 0;
+  a.out_dead = (o.out_dead && o.pool_inv && !bwd) ? 1 : 0;
   // bf16 rows are read / written in 4-channel words, and a ReLU mask comes as sign bytes (never the fp32 output)
   if (o.in_bf16 && (CQ % 4 != 0 || (mask && !o.mask_bits))) return MVH_OK;
   if ((o.out_bf16 || o.pooled_bf16) && CO % 4 != 0) return MVH_OK;

@@ -6,9 +6,14 @@
 //     dW_k[ci][co] = sum_{b,v} T_k(L) x [b,v,ci] * dpre[b,v,co]
 // therefore needs T_k(L) x only at those rows.  Two kernels:
 //   k_cheb_tstack : ONE workgroup per mesh runs the K-order recurrence on the (<= 4 channel) input in
-//                   the 160 KB LDS image of the other LDS kernels and stores T_k x of every vertex:
-//                   stack [B][N+1][K][4] (row N collects the padding slots; storing only the selected
-//                   rows needs a divergent store per vertex and order, which cost 214 spilled VGPRs).
+//                   the 160 KB LDS image of the other LDS kernels and stores T_k x of the SELECTED rows only,
+//                   as one plane per order: stack [B][K][n_sel + 1][4].  Which vertex a thread slot owns is free, so
+//                   slots 0 .. n_sel-1 own the selected vertices in pooled-row order (slot r = vertex D.col[r]) and
+//                   the remaining slots the un-selected ones (an in-kernel prefix sum over D's inverse map): the
+//                   stores are the first ceil(n_sel / THREADS) slots of every thread -- no divergent store, and a
+//                   wave stores 1 KB of consecutive bytes.  (Round 2 stored every vertex as [B][N+1][K][4]: each
+//                   lane's 16 bytes in a 96-byte-strided line of its own -- 122 MB of partial-line writes per launch
+//                   for the 7.7 MB k_stack_dw reads, 48.6 us; profiles/r02_h_pmc.json.)
 //                   64 workgroups: it leaves 3/4 of the chip to the small kernels of the main chain,
 //                   which is where the step engine schedules it.
 //   k_stack_dw    : streaming reduction  stack^T * (dout masked by the ReLU sign bytes)  over the
@@ -27,12 +32,49 @@ struct TstackDims {
 template <int VPT, int TCT, int PW>
 __global__ void __launch_bounds__(TCT)
 k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowinfo, const uint32_t* __restrict__ p_ell,
-              float* __restrict__ p_stack, TstackDims a) {
+              const int32_t* __restrict__ p_sel_inv, const int32_t* __restrict__ p_sel_col, float* __restrict__ p_stack,
+              TstackDims a) {
   constexpr int THREADS = TCT, VS = VPT * THREADS;
   extern __shared__ __align__(16) unsigned char smem[];
   float4* slab = reinterpret_cast<float4*>(smem);     // [VS] scaled t~_k = D^-1/2 T_k x; rows >= N stay zero
   uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]
-  const int mesh = blockIdx.x, tid = threadIdx.x, N = a.N;
+  const int mesh = blockIdx.x, tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
+
+  // ---- slot -> vertex: slots [0, n_sel) = the selected vertices in pooled-row order, [n_sel, N) = the others in
+  //      ascending order, slots >= N own the zero rows N .. VS-1.  The list of un-selected vertices is built in the
+  //      (not yet staged) ELL area: thread t counts them in its chunk [t VPT, (t + 1) VPT), block-wide exclusive scan.
+  uint16_t* rest = reinterpret_cast<uint16_t*>(ellv);          // [N - n_sel] un-selected vertex ids
+  int* wsum = reinterpret_cast<int*>(rest + VS);               // [THREADS / 64] per-wave totals
+  {
+    int flag[VPT], cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int v = tid * VPT + j;
+      flag[j] = (v < N && p_sel_inv[min(v, N - 1)] < 0) ? 1 : 0;
+      cnt += flag[j];
+    }
+    int inc = cnt;  // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - cnt;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+      if (flag[j]) rest[base++] = (uint16_t)(tid * VPT + j);
+    __syncthreads();
+  }
+  int vid[VPT];
+#pragma unroll
+  for (int vi = 0; vi < VPT; ++vi) {
+    const int slot = tid + vi * THREADS;
+    vid[vi] = slot < a.n_sel ? p_sel_col[slot] : (slot < N ? (int)rest[slot - a.n_sel] : slot);
+  }
+  __syncthreads();  // the list has been read: the area becomes the ELL image
   {
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
     const uint4 pad4 = make_uint4(pad, pad, pad, pad);
@@ -41,11 +83,16 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
   }
   float ka2[VPT], inv_s[VPT];
   float4 R[VPT];
-  float* const sbase = p_stack + (long long)mesh * (N + 1) * a.K * 4;
+  // plane k of this mesh: [n_sel][4]; slot r < n_sel stores row r (consecutive lanes -> consecutive 16 bytes)
+  // (every plane has one more row, n_sel: the slots past n_sel of the storing slot range write there -- unconditional
+  //  stores; a predicated store per vertex and order cost 186 spilled VGPRs)
+  constexpr int kStoreSlots = (1536 + THREADS - 1) / THREADS;   // slots of a thread that may own selected vertices: n_sel <= 1536 (host check)
+  const int prow = a.n_sel + 1;
+  float4* const sbase = reinterpret_cast<float4*>(p_stack) + (long long)mesh * a.K * prow;
   const float* xb = p_x + (long long)mesh * N * a.Cin;
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
-    const int v = tid + vi * THREADS;
+    const int v = vid[vi];
     const bool valid = v < N;
     const int vl = min(v, N - 1);
     const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
@@ -57,7 +104,7 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     for (int c = 0; c < 4; ++c)  // branch-free (clamped index, selected afterwards): the vertices' loads overlap
       t[c] = (c < a.Cin) ? xb[(long long)vl * a.Cin + min(c, a.Cin - 1)] : 0.f;
     if (!valid) t[0] = t[1] = t[2] = t[3] = 0.f;
-    *reinterpret_cast<float4*>(sbase + (long long)min(v, N) * a.K * 4) = make_float4(t[0], t[1], t[2], t[3]);  // T_0 x = x
+    if (vi < kStoreSlots) sbase[min(tid + vi * THREADS, a.n_sel)] = make_float4(t[0], t[1], t[2], t[3]);  // T_0 x = x
     slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -92,7 +139,7 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
-      const float4 g = gather(tid + vi * THREADS);
+      const float4 g = gather(vid[vi]);
       const float kk = ka2[vi] * sc;
       R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
                           fmaf(kk, g.w, -R[vi].w));
@@ -100,13 +147,14 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     __syncthreads();  // every gather of t~_{k-1} is done
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
-      const int v = tid + vi * THREADS;
+      const int v = vid[vi];
       const float4 old = slab[v];
       const float4 cur = R[vi];
       slab[v] = cur;
       R[vi] = old;
-      *reinterpret_cast<float4*>(sbase + ((long long)min(v, N) * a.K + k) * 4) =
-          make_float4(cur.x * inv_s[vi], cur.y * inv_s[vi], cur.z * inv_s[vi], cur.w * inv_s[vi]);
+      if (vi < kStoreSlots)
+        sbase[(long long)k * prow + min(tid + vi * THREADS, a.n_sel)] =
+            make_float4(cur.x * inv_s[vi], cur.y * inv_s[vi], cur.z * inv_s[vi], cur.w * inv_s[vi]);
     }
     __syncthreads();
   }
@@ -147,7 +195,7 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
     const int r = base + ty;
     if (r >= r1) return;
     const int b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
-    if (tx < a.K) pa = *reinterpret_cast<const float4*>(stack + (((long long)b * (a.N + 1) + v) * a.K + tx) * 4);
+    if (tx < a.K) pa = *reinterpret_cast<const float4*>(stack + (((long long)b * a.K + tx) * (a.n_sel + 1) + (r - b * a.n_sel)) * 4);
     if (tx < CQ4) {
       float4 d = load4_any(dout, (long long)r * a.Cout + tx * 4, a.dout_bf16 != 0);
       if (bits) {
@@ -202,18 +250,19 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
   }
 }
 
-// workspace: the stack [B][N+1][K][4], then the per-block partials of the reduction
-size_t tstack_stack_floats(int B, int N, int K) { return (size_t)B * (N + 1) * K * 4; }
-size_t tstack_ws_floats(int B, int N, int K, int Cin, int Cout) {
+// workspace: the stack [B][K][n_sel + 1][4] (row n_sel of a plane is the store target of the unselected slots), then the
+// per-block partials of the reduction
+size_t tstack_stack_floats(int B, int n_sel, int K) { return (size_t)B * (n_sel + 1) * K * 4; }
+size_t tstack_ws_floats(int B, int n_sel, int K, int Cin, int Cout) {
   (void)Cin;
-  return tstack_stack_floats(B, N, K) + (size_t)kSdwGrid * ((size_t)(K + 1) * Cout * 4) + 64;
+  return tstack_stack_floats(B, n_sel, K) + (size_t)kSdwGrid * ((size_t)(K + 1) * Cout * 4) + 64;
 }
 
 bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K) {
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap || !pool || !lap->rowinfo || !lap->ell || (lap->flags & need) != need) return false;
   if (lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & MVH_CSR_ELL_OVERFLOW)) return false;
-  if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0) return false;
+  if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0 || pool->n_rows > 3 * 512) return false;
   if (Cin < 1 || Cin > 4 || Cout < 4 || Cout > 32 || Cout % 4 != 0 || K < 1 || K > 8) return false;
   if (K * Cin * Cout + Cout > 512) return false;
   if (N + 1 <= 2048 || N + 1 > 5120) return false;  // only the 160 KB configuration pays: smaller levels keep the LDS dW kernel
@@ -222,15 +271,18 @@ bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin
   return true;
 }
 
-// stack [B][N+1][K][4] <- T_k(L) x
+// stack [B][K][n_sel][4] <- T_k(L) x at the selected rows
 int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
                   int N, int Cin, int K) {
   TstackDims d{B, N, K, Cin, pool->n_rows};
   const size_t lds = (size_t)5120 * (16 + 4 * 4);
-  auto kern = k_cheb_tstack<10, 512, 4>;  // 256 VGPRs per lane: the 1024 x 5 shape spilled 86 of its 128
-  static LdsAttr attr;
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
-  hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, st, x, lap->rowinfo, lap->ell, stack, d);
+  // 512 threads x 10 vertices; debug switch tstack_tall: 1024 x 5 (61 VGPRs, 4 waves per SIMD) -- MEASURED the same within
+  // the noise of one box (550.1 vs 546.9 us per step over four alternating runs)
+  const bool wide = dbg().tstack_tall == 0;
+  auto kern = wide ? k_cheb_tstack<10, 512, 4> : k_cheb_tstack<5, 1024, 4>;
+  static LdsAttr attr[2];   // (one per kernel)
+  if (int rc = attr[wide ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(wide ? 512 : 1024), lds, st, x, lap->rowinfo, lap->ell, pool->sel_inv, pool->col, stack, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

@@ -11,6 +11,33 @@
 
 #include "meshvae_hip.h"
 
+// In-kernel stamps of the diagnostic build (make STAMP=1): every wave's lane 0 writes s_memtime into
+// g_mvh_stamp[(block * 16 + wave) * 32 + slot]; MVH_STAMP_READER(name) in the instrumented file copies them out.
+// In the product build MVH_STAMPX expands to nothing.
+#ifdef MVH_STAMP
+static __device__ unsigned long long g_mvh_stamp[512 * 16 * 32];   // (no relocatable device code: one table per translation unit)
+// the instrumented translation unit exports its reader under its own name (diagnostic build only, not in the header)
+#define MVH_STAMP_READER(name)                                                                                  \
+  extern "C" int name(unsigned long long* host, int clear) {                                                    \
+    if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mvh_stamp), sizeof(g_mvh_stamp)) != hipSuccess) return 1; \
+    void* p__ = nullptr;                                                                                        \
+    if (clear && (hipGetSymbolAddress(&p__, HIP_SYMBOL(g_mvh_stamp)) != hipSuccess ||                            \
+                  hipMemset(p__, 0, sizeof(g_mvh_stamp)) != hipSuccess)) return 1;                               \
+    return 0;                                                                                                   \
+  }
+#define MVH_STAMPX(slot)                                                                                      \
+  do {                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    unsigned long long t__;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 512 && (slot) < 32)                                           \
+      g_mvh_stamp[((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 32 + (slot)] = t__;                     \
+  } while (0)
+#else
+#define MVH_STAMPX(slot) do { } while (0)
+#endif
+
 namespace mvh {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
@@ -82,6 +109,9 @@ struct DebugCfg {
   int no_bwd_fused = 0;    // ... and its dW / dX as two kernels reading two stacks instead of one pass over T_k(dpre)
   int no_dw_rows = 0;      // streaming levels: un-pool the gradient with its own launch, reduce the weight gradient over all rows
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
+  int dw_lane2 = 0;        // 1: the small levels' conv weight gradients alternate between the two gradient lanes
+  int tstack_tall = 0;     // 1: k_cheb_tstack as 1024 threads x 5 vertices instead of 512 x 10
+  int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
 
@@ -128,6 +158,7 @@ struct LdsConvOpts {
   // bf16 STORAGE of the activation tensors (bf16.hpp): `in`, `out` (backward with out_pool_t: the pooled buffer) and
   // `pooled` are then 2-byte tensors behind the float pointers; arithmetic and the LDS state stay fp32
   bool in_bf16 = false, out_bf16 = false, pooled_bf16 = false;
+  bool out_dead = false;                   // with pool_inv: store only the selected rows (pooled) and their sign bytes
   const uint32_t* prepacked_h = nullptr;   // bf16 weight slabs of cheb_l0h.hip already built (launch_pack_all)
 };
 // level-0 16 -> 16 forward / dX on bf16 rows with the contraction on the matrix pipe (cheb_l0h.hip)
@@ -173,6 +204,11 @@ struct ConvIO {
                                                         // layout in the forward, W^T layout in the backward) or null
   float* s_keep = nullptr;                              // split path + deferred reduction: where S [Cin*Cout] may stay
                                                         // until launch_dw_reduce_all (the scratch is reused before)
+  // forward with a fused one-hot pooling: nobody reads the output rows the pooling does NOT select, nor their sign
+  // bytes (the encoder: the next layer takes the pooled tensor, the backward masks the un-pooled gradient, which is
+  // zero off the selected rows) -- the LDS-resident kernel then stores the pooled rows and their sign bytes only (a
+  // quarter of the epilogue's stores, 20 MB less HBM traffic at the 5k level); every other path ignores the hint
+  bool out_dead = false;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
@@ -210,8 +246,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool x_bf16 = false, bool dout_bf16 = false /* storage type of x / dout (bf16.hpp) */);
 
 // first-layer weight gradient through a saved Chebyshev stack (cheb_tstack.hip)
-size_t tstack_stack_floats(int B, int N, int K);
-size_t tstack_ws_floats(int B, int N, int K, int Cin, int Cout);
+size_t tstack_stack_floats(int B, int n_sel, int K);   // (n_sel = rows the pooling selects = pool->n_rows)
+size_t tstack_ws_floats(int B, int n_sel, int K, int Cin, int Cout);
 bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K);
 int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
                   int N, int Cin, int K);

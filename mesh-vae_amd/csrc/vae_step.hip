@@ -24,7 +24,7 @@ struct StepPlan {
   // activations (floats): conv outputs / pooled, decoder unpooled / conv outputs
   std::vector<size_t> encA, encP, decU, decC, g_encA, g_encP, g_decU, g_decC;
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat, d_heads;
-  size_t scratch_main, scratch_side, scratch_bytes;
+  size_t scratch_main, scratch_side, scratch_side2, scratch_bytes;   // (scratch_side2: second gradient lane, kNoBits at streaming levels)
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
   std::vector<size_t> dwPartEnc, dwPartDec;  // per-layer dW partial tiles (reduced together after the join)
   std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
@@ -96,7 +96,7 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
     p.pk_h_f = take(cur, l0h_pack_dwords(d->K[n - 1]));
     p.pk_h_b = take(cur, l0h_pack_dwords(d->K[n - 1]));
   }
-  p.tstack = take(cur, tstack_ws_floats(B, p.Nn[0], d->K[0], p.f[0], p.f[1]));
+  p.tstack = take(cur, tstack_ws_floats(B, p.Nn[1], d->K[0], p.f[0], p.f[1]));   // (use_tstack requires down[0].n_rows == Nn[1])
   p.dwPartEnc.resize(n); p.dwPartDec.resize(n); p.dwPartBytesEnc.resize(n); p.dwPartBytesDec.resize(n);
   for (int i = 0; i < n; ++i) {
     p.dwPartBytesEnc[i] = cheb_dw_lds_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]);
@@ -124,6 +124,8 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.scratch_bytes = align_up(scratch, 256);
   p.scratch_main = cur; cur += p.scratch_bytes;
   p.scratch_side = cur; cur += p.scratch_bytes;
+  p.scratch_side2 = kNoBits;
+  if (p.Nn[0] + 1 <= 5120) { p.scratch_side2 = cur; cur += p.scratch_bytes; }   // (the streaming levels' scratch is GBs: no second lane there)
   p.total = cur + 256;
   return MVH_OK;
 }
@@ -303,6 +305,8 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
     ConvIO io;
     io.x = bf && i > 0; io.out = bf; io.pooled = bf && i + 1 < n;   // (the last pooled level feeds the fp32 dense head)
+    // the un-pooled rows have no reader (the backward takes the ReLU signs from the sign bytes, and only at the pooled rows)
+    io.out_dead = p.encBits[i] != kNoBits && !dbg().keep_enc_out;
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]),
                            bf ? nullptr : TX(p.txEnc[i]), B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
@@ -441,6 +445,10 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   hipStream_t dstream = (sstream == main) ? main : (side_stream ? sstream : side->dense);
   void* sm = (char*)ws + p.scratch_main;
   void* ss = (char*)ws + p.scratch_side;
+  // debug switch dw_lane2: the small levels' conv weight gradients alternate between the conv lane and the dense lane
+  const bool lane2 = dbg().dw_lane2 && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits;
+  void* ss2 = lane2 ? (void*)((char*)ws + p.scratch_side2) : ss;
+  int lane_toggle = 0;
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
   const bool bf = d->storage == MVH_STORAGE_BF16;   // bf16 activations and activation gradients (see the forward)
   const float* u_cls = drop_u ? drop_u + (size_t)B * p.H : nullptr;
@@ -471,18 +479,24 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   };
   PendingDw pending[4];
   int n_pending = 0;
+  hipStream_t sstream_conv = sstream;
+  void* ss_conv = ss;
   const int fork_batch = dbg().fork_batch < 1 ? 1 : (dbg().fork_batch > 4 ? 4 : dbg().fork_batch);
   auto flush_dw = [&](bool also_dense) -> int {  // one event for everything queued (+ the dense lane)
     if (n_pending == 0 && !also_dense) return MVH_OK;
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
       if (n_pending > 0) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
-      if (also_dense && (dstream != sstream || n_pending == 0)) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
+      if ((also_dense && (dstream != sstream || n_pending == 0)) || (lane2 && n_pending > 0))
+        MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
     for (int q = 0; q < n_pending; ++q) {
       const PendingDw& w = pending[q];
       bool deferred = false, fused = false;
+      hipStream_t sstream = sstream_conv;      // (shadows: this item's lane)
+      void* ss = ss_conv;
+      if (lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1)) { sstream = dstream; ss = ss2; }
       const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
       const float* dout = w.dout;
       if (w.dout_pool) {
@@ -671,7 +685,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     if (use_tstack) {  // dW_0 = stack^T dpre over the pooled rows only: a 5 us streaming reduction
       if (ev_tstack) MVH_HIP(hipStreamWaitEvent(main, ev_tstack, 0));
       TRY(launch_stack_dw(main, &d->down[0], F(p.tstack), F(p.g_encP[0]), BITS(p.encBits[0]), F(p.encA[0]),
-                          G[ix.encW(0)], G[ix.encB(0)], F(p.tstack) + tstack_stack_floats(B, p.Nn[0], d->K[0]), B, p.Nn[0],
+                          G[ix.encW(0)], G[ix.encB(0)], F(p.tstack) + tstack_stack_floats(B, p.Nn[1], d->K[0]), B, p.Nn[0],
                           p.f[0], p.f[1], d->K[0], &red.e[red.n], io.dout));
       ++red.n;
       if (tail_on_main && n > 1) {

@@ -101,7 +101,7 @@ def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat, dtype=torch.float32
                 z=zo.detach(), y_hat=yo.detach(), grads=ora.grads(), pre=ora.pre)
 
 
-def _relu_ties(nat, net, want, drop_u, tag):
+def _relu_ties(nat, net, want, drop_u, tag, topo_name):
     """Two fp32 evaluation orders disagree on the sign of a pre-activation that is zero to rounding (measured: B = 64
     meshes of the 5k model have 15 M ReLU inputs of magnitude O(1); about one per step lies within 1e-7 of zero, e.g.
     2.5e-8 in float64), and the ReLU derivative is discontinuous there, so ONE such element moves every upstream
@@ -113,13 +113,21 @@ def _relu_ties(nat, net, want, drop_u, tag):
     n, B = net.n_layers, nat.B
     H, flat = net.num_hidden, net.dec_lin_2.out_features
     blocks = _drop_blocks(drop_u, B, H, flat)
-    sites = [(f"cheb.{i}", ("encA", i), None) for i in range(n)] + [(f"cheb_dec.{i}", ("decC", i), None) for i in range(n)]
+    # encoder convs: only the rows the one-hot pooling selects exist (and matter: the ReLU of an un-selected row feeds
+    # nothing) -- the step stores the pooled tensor encP[i] = relu(pre)[:, D_i.col]
+    topo = np.load(os.path.join(ROOT, "tests", "golden", topo_name))
+    sites = [(f"cheb.{i}", ("encP", i), None) for i in range(n)] + [(f"cheb_dec.{i}", ("decC", i), None) for i in range(n)]
     sites += [("enc_lin", ("h", 0), blocks[0]), ("dec_lin", ("d1", 0), blocks[2]), ("dec_lin_2", ("d2", 0), blocks[3])]
     pins, notes = {}, []
     for site, (name, idx), u in sites:
         pre = want["pre"][site]
-        ours = nat.ws_tensor(name, idx).cpu().reshape(pre.shape) > 0
         theirs = pre > 0
+        if name == "encP":
+            sel = torch.from_numpy(topo[f"D{idx}_col"].astype(np.int64))
+            ours = theirs.clone()
+            ours[:, sel] = nat.ws_tensor(name, idx).cpu().reshape(pre.shape[0], len(sel), pre.shape[2]) > 0
+        else:
+            ours = nat.ws_tensor(name, idx).cpu().reshape(pre.shape) > 0
         diff = ours != theirs
         if u is not None:                       # a dropped element says nothing about the ReLU decision
             diff &= (u >= P_DROP)
@@ -176,7 +184,7 @@ def test_b64_fp32_step_matches_oracle_on_all_meshes():
     nat, got = _native(net, B, x, y, eps, drop_u)
     assert nat.u_cols == 3 * H + flat
     want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat)
-    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 5k")
+    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 5k", "topology_5k.npz")
     if pins:
         want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
     truth = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat, dtype=torch.float64, pins=pins)
@@ -226,7 +234,7 @@ def test_b64_hires20k_step_matches_oracle_on_all_meshes():
     drop_u = torch.rand(B * (3 * H + flat), generator=g)
     nat, got = _native(net, B, x, y, eps, drop_u)
     want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat)
-    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k")
+    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k", "topology_20k.npz")
     if pins:
         want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
     truth = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, dtype=torch.float64, pins=pins)
