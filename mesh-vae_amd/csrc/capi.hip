@@ -40,7 +40,8 @@ static const DebugKey kDebugKeys[] = {
     {"no_dx_tstack", &DebugCfg::no_dx_tstack},   {"no_dx_first", &DebugCfg::no_dx_first},
     {"no_bwd_fused", &DebugCfg::no_bwd_fused},   {"no_dw_rows", &DebugCfg::no_dw_rows},
     {"keep_enc_out", &DebugCfg::keep_enc_out},   {"dw_lane2", &DebugCfg::dw_lane2},
-    {"tstack_tall", &DebugCfg::tstack_tall},
+    {"tstack_tall", &DebugCfg::tstack_tall},     {"prefetch_at", &DebugCfg::prefetch_at},
+    {"dw_tie_x", &DebugCfg::dw_tie_x},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

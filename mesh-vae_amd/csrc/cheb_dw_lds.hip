@@ -96,6 +96,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const int mesh = (jj / per_mesh) * 8 + xcd, sl = rem / QP, s0 = sl * 4, q0 = 4 * (rem % QP);
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
+  MVH_STAMPX(0);
 
   if constexpr (!kDB) {  // stage the vertex-major ELL lists with 16-byte copies; slots past N point at the zero row N
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
@@ -107,6 +108,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   }
 
+  MVH_STAMPX(1);
   // ---- Q rows in the MFMA layout: lane (b = lane>>2, i = lane&3) of step s holds
   //      Q[v][16h + 4i .. +3] / s_v  for vertex v = 16 (s NW + wave) + b
   float4 qreg[SPLIT ? 1 : STEPS_CT][QH];
@@ -126,9 +128,10 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   // Fast path of the train step's decoder layers (sign bytes, no row map, full channel groups): the loop
   // body is branch-free, so the scheduler can keep the loads of many steps in flight; the general loop
   // below has wave-uniform branches per step, which serialise its 40 global loads at the 5k level.
-  const bool fast_q = !SPLIT && Qbits != nullptr && a.map_side != 2 && (CQ % 16 == 0);
-  auto load_q_fast = [&](auto bf_tag) {
+  const bool fast_q = !SPLIT && (Qbits != nullptr || Qm == nullptr) && a.map_side != 2 && (CQ % 16 == 0);
+  auto load_q_fast = [&](auto bf_tag, auto bits_tag) {
     constexpr bool kBF = decltype(bf_tag)::value;
+    constexpr bool kBits = decltype(bits_tag)::value;   // Q carries a ReLU mask as sign bytes (else: no mask at all)
 #pragma unroll
     for (int s = 0; s < STEPS_CT; ++s) {
       const int v = 16 * (s * NW + wave) + (lane >> 2);
@@ -143,11 +146,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         float4 t;
         if constexpr (kBF) t = bf16_unpack4(*reinterpret_cast<const uint2*>(Qh + (long long)vl * CQ + c0));
         else t = *reinterpret_cast<const float4*>(Qb + (long long)vl * CQ + c0);
-        const uint32_t m = Qbits[vl * (CQ / 4) + (c0 >> 2)];
-        t.x = (m & 1u) ? t.x : 0.f;
-        t.y = (m & 2u) ? t.y : 0.f;
-        t.z = (m & 4u) ? t.z : 0.f;
-        t.w = (m & 8u) ? t.w : 0.f;
+        if constexpr (kBits) {
+          const uint32_t m = Qbits[vl * (CQ / 4) + (c0 >> 2)];
+          t.x = (m & 1u) ? t.x : 0.f;
+          t.y = (m & 2u) ? t.y : 0.f;
+          t.z = (m & 4u) ? t.z : 0.f;
+          t.w = (m & 8u) ? t.w : 0.f;
+        }
         qsum[h].x = fmaf(live, t.x, qsum[h].x);
         qsum[h].y = fmaf(live, t.y, qsum[h].y);
         qsum[h].z = fmaf(live, t.z, qsum[h].z);
@@ -157,8 +162,13 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   };
   if (fast_q) {
-    if (a.q_bf16) load_q_fast(std::true_type{});
-    else load_q_fast(std::false_type{});
+    if (Qbits) {
+      if (a.q_bf16) load_q_fast(std::true_type{}, std::true_type{});
+      else load_q_fast(std::false_type{}, std::true_type{});
+    } else {
+      if (a.q_bf16) load_q_fast(std::true_type{}, std::false_type{});
+      else load_q_fast(std::false_type{}, std::false_type{});
+    }
   } else
 #pragma unroll
   for (int s = 0; s < STEPS_CT; ++s) {
@@ -210,6 +220,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   }
 
+  MVH_STAMPX(2);
   float* part = p_part + (((long long)sl * a.B + mesh) * NW + wave) * (long long)(a.K + 1) * CQT * 4;
   // bias gradient (plane K of the tile set, layout [q][j]): column sums of Q, written right away
   if (a.db_mode == 1 && sl == 0) {  // lane (b, i) holds q = 16h + 4i + {0..3}  (split: q0 + i)
@@ -231,6 +242,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     }
   }
 
+  MVH_STAMPX(3);
   // ---- own vertices (thread-owns-vertex layout): t~_0 = s P[:, slab]
   float ka2[VPT];
   float4 R[VPT];
@@ -355,7 +367,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       if (lane == 0) pk[c] = x;
     }
   }
+  MVH_STAMPX(4);
   __syncthreads();  // slab = t~_0, ELL staged
+  MVH_STAMPX(5);
 
   auto gather = [&](int v, int vi, const float4* slab) {  // (shadows the kernel's `slab`: the slab to gather from)
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -444,6 +458,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   };
 
   mfma_pass(0, reinterpret_cast<const float*>(slab));
+  MVH_STAMPX(6);
   if constexpr (kDB) {
     float4* cur = slab;   // t~_{k-1}
     float4* oth = slabB;  // t~_{k-2}, becomes t~_k (own rows only)
@@ -473,7 +488,9 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
                             fmaf(kk, g.w, -R[vi].w));
       }
+      MVH_STAMPX(3 + 4 * k);
       __syncthreads();  // all reads of t~_{k-1} (gathers and the previous MFMA pass) are done
+      MVH_STAMPX(4 + 4 * k);
 #pragma unroll
       for (int vi = 0; vi < VPT; ++vi) {
         const int v = tid + vi * THREADS;
@@ -482,10 +499,20 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
         R[vi] = old;
       }
       __syncthreads();
+      MVH_STAMPX(5 + 4 * k);
       mfma_pass(k, reinterpret_cast<const float*>(slab));
+      MVH_STAMPX(6 + 4 * k);
     }
   }
+#ifdef MVH_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MVH_STAMPX(30);
 }
+
+#ifdef MVH_STAMP
+MVH_STAMP_READER(mvh_debug_read_stamps_dw)
+#endif
 
 // Sum the per-(mesh, wave) partial tiles in fixed order and scatter into dW [K][Cin][Cout] / db.
 // part layout [slab][mesh*NW + wave][tile]; one block = 64 consecutive tile entries x 16 groups
@@ -625,8 +652,10 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (!lap->rowinfo || !lap->ell || lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & need) != need)
     return MVH_OK;
   if (N < 1 || N + 1 >= 65535 || B < 1) return MVH_OK;
-  // P = the side with fewer channels runs the recurrence (ties: x); Q stays in registers
-  const bool p_is_x = Cin <= Cout;
+  // P = the side with fewer channels runs the recurrence; Q stays in registers.  Ties: dout, whose ReLU mask then costs
+  // one byte per vertex on the slab side instead of one per vertex and lane group on the register side (MEASURED: 549.4 vs
+  // 554.3 us per step in three alternating runs; debug switch dw_tie_x = round 2's choice, x)
+  const bool p_is_x = Cin < Cout || (Cin == Cout && dbg().dw_tie_x);
   const int CP = p_is_x ? Cin : Cout, CQ = p_is_x ? Cout : Cin;
   if (CQ != 8 && CQ != 16 && CQ != 32) return MVH_OK;
   if (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)out_mask) % 16 != 0) return MVH_OK;

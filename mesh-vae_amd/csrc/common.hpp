@@ -111,6 +111,8 @@ struct DebugCfg {
   int no_head_fuse = 0;    // dec_lin (forward and dX) as its own GEMM launch instead of inside the latent-head kernels
   int dw_lane2 = 0;        // 1: the small levels' conv weight gradients alternate between the two gradient lanes
   int tstack_tall = 0;     // 1: k_cheb_tstack as 1024 threads x 5 vertices instead of 512 x 10
+  int prefetch_at = 0;     // encoder stage behind which the forward launches the armed first-layer stack (MEASURED 0..3: 553-555 us, no difference)
+  int dw_tie_x = 0;        // LDS dW kernel, Cin == Cout: the recurrence runs on x and dout stays in registers (round 2's choice)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();

@@ -312,7 +312,10 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
                            &d->down[i], F(p.encP[i]), BITS(p.encBits[i]), nullptr, io));
     cur = F(p.encP[i]);
-    if (i == 0 && phases == kPhAll) TRY(run_armed_prefetch(side_for_device(), (hipStream_t)stream, d, p, x, ws, B));
+    // the armed first-layer stack (mvh_vae_backward_prefetch) starts behind encoder stage `prefetch_at` (debug switch;
+    // default: the last one, so that its 64 workgroups run beside the dense head and the coarsest decoder stages)
+    if (i == min(max(dbg().prefetch_at, 0), n - 1) && phases == kPhAll)
+      TRY(run_armed_prefetch(side_for_device(), (hipStream_t)stream, d, p, x, ws, B));
   }
   if (phases & kPhEnc)
     TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], h_out ? h_out : F(p.h), B, p.flat, p.H, MVH_ACT_RELU,

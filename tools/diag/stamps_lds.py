@@ -11,7 +11,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=16); ap.add_argument("--cout", type=int, default=16)
 ap.add_argument("--k", type=int, default=6); ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--level", type=int, default=0); ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--level", type=int, default=0); ap.add_argument("--bwd", action="store_true"); ap.add_argument("--dw", action="store_true")
 args = ap.parse_args()
 from meshvae_hip import check, lib, topology
 from meshvae_hip.functional import workspace
@@ -31,11 +31,15 @@ signs = torch.empty(B, N, max(Cout // 4, 1), dtype=torch.uint8, device=dev)
 wsb = max(L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K))
 ws = workspace(wsb, dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-rd = L.mvh_debug_read_stamps_lds
+dW, db = torch.empty_like(W), torch.empty_like(bias)
+rd = L.mvh_debug_read_stamps_dw if args.dw else L.mvh_debug_read_stamps_lds
 rd.restype, rd.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
 
 def run():
-    if args.bwd:
+    if args.dw:
+        check(L.mvh_cheb_conv_bwd_signs(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(), signs.data_ptr(),
+                                        dout.data_ptr(), None, dW.data_ptr(), db.data_ptr(), B, N, Cin, Cout, K, ws.data_ptr(), wsb))
+    elif args.bwd:
         check(L.mvh_cheb_conv_bwd_signs(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(), signs.data_ptr(),
                                         dout.data_ptr(), dx.data_ptr(), None, None, B, N, Cin, Cout, K, ws.data_ptr(), wsb))
     else:
@@ -54,7 +58,7 @@ t = buf.reshape(512, 16, 32).astype(np.float64)
 used = t[:, :, 0] > 0
 t0 = t[:, :, 0][used].min()
 span = t[used].max() - t0
-print(f"{'dX' if args.bwd else 'fwd'} N={N} {Cin}->{Cout} K={K} B={B}: event time {e0.elapsed_time(e1) * 1e3:.1f} us (diagnostic build), stamp span {span:.0f} ticks, "
+print(f"{'dW' if args.dw else 'dX' if args.bwd else 'fwd'} N={N} {Cin}->{Cout} K={K} B={B}: event time {e0.elapsed_time(e1) * 1e3:.1f} us (diagnostic build), stamp span {span:.0f} ticks, "
       f"{int(used.sum())} waves stamped")
 slots = [s for s in range(32) if (t[:, :, s][used] > 0).all()]
 print("slots present:", slots)
