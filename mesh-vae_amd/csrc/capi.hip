@@ -1,5 +1,7 @@
 // C-ABI glue: error reporting, argument validation and the thin entry points
 // (propagate / pool) that map 1:1 onto the sparse kernel.
+#include <dlfcn.h>
+
 #include "common.hpp"
 
 namespace mvh {
@@ -41,7 +43,7 @@ static const DebugKey kDebugKeys[] = {
     {"no_bwd_fused", &DebugCfg::no_bwd_fused},   {"no_dw_rows", &DebugCfg::no_dw_rows},
     {"keep_enc_out", &DebugCfg::keep_enc_out},   {"dw_lane2", &DebugCfg::dw_lane2},
     {"tstack_tall", &DebugCfg::tstack_tall},     {"prefetch_at", &DebugCfg::prefetch_at},
-    {"dw_tie_x", &DebugCfg::dw_tie_x},
+    {"dw_tie_x", &DebugCfg::dw_tie_x},           {"roctx", &DebugCfg::roctx},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {
@@ -90,6 +92,42 @@ extern "C" int32_t mvh_debug_get(const char* key) {
   int DebugCfg::*f = key ? find_debug_key(key, strlen(key)) : nullptr;
   return f ? dbg().*f : -1;
 }
+
+namespace mvh {
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+std::atomic<int> g_roctx_state{0};   // 0 not tried, 1 loaded, -1 unavailable
+bool roctx_ready() {
+  int s = g_roctx_state.load(std::memory_order_acquire);
+  if (s == 0) {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    roctx_push_t pu = h ? (roctx_push_t)dlsym(h, "roctxRangePushA") : nullptr;
+    roctx_pop_t po = h ? (roctx_pop_t)dlsym(h, "roctxRangePop") : nullptr;
+    if (pu && po) { g_roctx_push = pu; g_roctx_pop = po; s = 1; } else s = -1;
+    g_roctx_state.store(s, std::memory_order_release);
+  }
+  return s == 1;
+}
+}  // namespace
+RoctxRange::RoctxRange(const char* fmt, ...) : on(false) {
+  if (!dbg().roctx || !roctx_ready()) return;
+  char buf[96];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_roctx_push(buf);
+  on = true;
+}
+RoctxRange::~RoctxRange() {
+  if (on) g_roctx_pop();
+}
+}  // namespace mvh
 
 extern "C" int mvh_version(void) { return MVH_ABI_VERSION; }
 

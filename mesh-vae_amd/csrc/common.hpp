@@ -113,9 +113,20 @@ struct DebugCfg {
   int tstack_tall = 0;     // 1: k_cheb_tstack as 1024 threads x 5 vertices instead of 512 x 10
   int prefetch_at = 0;     // encoder stage behind which the forward launches the armed first-layer stack (MEASURED 0..3: 553-555 us, no difference)
   int dw_tie_x = 0;        // LDS dW kernel, Cin == Cout: the recurrence runs on x and dout stays in registers (round 2's choice)
+  int roctx = 0;           // 1: roctxRangePush / Pop around every layer of mvh_vae_forward / mvh_vae_backward (MVH_RANGE)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
+
+// roctx range around the enqueue of one layer / phase of the step (rocprofv3 --marker-trace attributes the kernels
+// launched inside it): active only under the debug switch `roctx` (the marker library, librocprofiler-sdk-roctx.so, is
+// loaded with dlopen on first use; without the switch the constructor is one predictable branch).
+struct RoctxRange {
+  bool on;
+  RoctxRange(const char* fmt, ...);
+  ~RoctxRange();
+};
+#define MVH_RANGE(...) ::mvh::RoctxRange mvh_range__(__VA_ARGS__)
 
 // ---- internal launchers shared between translation units (all async on `st`)
 int launch_spmm(hipStream_t st, const mvh_csr_t* op, const float* x, float* y, const float* add,

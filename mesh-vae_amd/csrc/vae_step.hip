@@ -297,12 +297,14 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
       add(P[ix.decW(n - 1)], p.pk_h_b, p.f[2], p.f[1], d->K[n - 1], true);
       t.e[t.n - 1].bwd = 4;
     }
+    MVH_RANGE("fwd pack");
     TRY(launch_pack_all((hipStream_t)stream, t));
   }
   // ---- encoder (cheb_VAE.py:261-273)
   const float* cur = x;
   for (int i = 0; i < n && (phases & kPhEnc); ++i) {
     // conv + ReLU + one-hot downsampling in one launch (the pooled rows are extra stores of the epilogue)
+    MVH_RANGE("fwd enc%d N=%d %d->%d", i, p.Nn[i], p.f[i], p.f[i + 1]);
     ConvIO io;
     io.x = bf && i > 0; io.out = bf; io.pooled = bf && i + 1 < n;   // (the last pooled level feeds the fp32 dense head)
     // the un-pooled rows have no reader (the backward takes the ReLU signs from the sign bytes, and only at the pooled rows)
@@ -312,17 +314,20 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
                            &d->down[i], F(p.encP[i]), BITS(p.encBits[i]), nullptr, io));
     cur = F(p.encP[i]);
-    // the armed first-layer stack (mvh_vae_backward_prefetch) starts behind encoder stage `prefetch_at` (debug switch;
-    // default: the last one, so that its 64 workgroups run beside the dense head and the coarsest decoder stages)
+    // the armed first-layer stack (mvh_vae_backward_prefetch) starts behind encoder stage `prefetch_at` (debug switch,
+    // default 0; MEASURED 0 .. 3 on one box: 553 .. 555 us per step, no difference)
     if (i == min(max(dbg().prefetch_at, 0), n - 1) && phases == kPhAll)
       TRY(run_armed_prefetch(side_for_device(), (hipStream_t)stream, d, p, x, ws, B));
   }
-  if (phases & kPhEnc)
+  if (phases & kPhEnc) {
+    MVH_RANGE("fwd enc_lin");
     TRY(mvh_linear_fwd(stream, cur, P[ix.encLW()], P[ix.encLB()], h_out ? h_out : F(p.h), B, p.flat, p.H, MVH_ACT_RELU,
                        u_enc, pd));
+  }
   // ---- classifier + latent heads + reparameterisation (cheb_VAE.py:203-226)
   bool d1_done = false;   // dec_lin rides in the latent-head launch when the step runs both (one launch less)
   if (phases & kPhHead) {
+    MVH_RANGE("fwd latent heads");
     const bool with_dec = (phases & kPhDec) && !zy_in;
     TRY(latent_fwd_impl((hipStream_t)stream, F(p.h), y, u_cls, pd, P[ix.clsW()], P[ix.clsB()], P[ix.zmW()], P[ix.zmB()],
                         P[ix.zvW()], P[ix.zvB()], eps, y_hat, mu, logvar, z, F(p.zy), B, p.H, p.C, p.Z,
@@ -341,6 +346,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
+    MVH_RANGE("fwd dec%d N=%d %d->%d", i, p.Nn[lvl], cin, cout);
     ConvIO io;
     io.x = io.out = io.pooled = bf;
     if (i == n - 1 && p.pk_h_f != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_f));
@@ -352,6 +358,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   }
   // final conv on the coarsest edge list (the reference's quirk, :288), no bias, no activation
   {
+    MVH_RANGE("fwd final conv N=%d %d->%d", p.Nn[0], p.f[1], p.f[0]);
     ConvIO io;
     io.x = bf;   // (the reconstruction itself is an fp32 tensor)
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
@@ -361,6 +368,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   if (!(phases & kPhLoss)) return MVH_OK;
   // ---- loss (cheb_VAE.py:321-346)
   // (the gradient seeds of a d_loss = 1 backward come out of the same two launches)
+  MVH_RANGE("fwd loss");
   return loss_fwd_impl((hipStream_t)stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld,
                        correct, B, p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes, F(p.g_recon), F(p.d_mu), F(p.d_lv),
                        F(p.d_yhat));
@@ -548,6 +556,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                          F(p.d_lv), F(p.d_yhat), B, p.Nn[0] * p.F0, p.C, p.Z));
   // ---- final conv
   {
+    MVH_RANGE("bwd final conv");
     const float* xin = F(p.decC[n - 1]);
     ConvIO io;
     io.x = bf; io.dx = bf;   // (g_recon is fp32)
@@ -563,6 +572,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // ---- decoder stages, last to first
   for (int i = n - 1; i >= 0; --i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
+    MVH_RANGE("bwd dec%d N=%d %d->%d", i, p.Nn[lvl], cin, cout);
     ConvIO io;
     io.x = io.dout = io.dx = bf;
     io.dx_pooled = bf && i > 0;   // (stage 0 hands its pooled gradient to the fp32 dense head)
@@ -655,6 +665,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // zero-filled [B, N_i, C] gradient tensor); if a layer is not eligible it is un-pooled explicitly.
   for (int i = n - 1; i >= 0; --i) {
     const float* xin = (i > 0) ? F(p.encP[i - 1]) : x;
+    MVH_RANGE("bwd enc%d N=%d %d->%d", i, p.Nn[i], p.f[i], p.f[i + 1]);
     ConvIO io;
     io.x = bf && i > 0; io.dout = bf && i + 1 < n; io.dx = bf;   // (the last level's gradient comes from the fp32 dense head)
     if (i > 0) {
@@ -740,6 +751,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     MVH_HIP(hipStreamWaitEvent(main, side->ev[ev], 0));
     ev = (ev + 1) % side->n_ev;
   }
+  MVH_RANGE("bwd reduce weight-gradient partials");
   TRY(launch_dw_reduce_all(main, red));  // every deferred dW / db in one launch
   return MVH_OK;
 }

@@ -1,0 +1,112 @@
+"""GPU (-m gpu): the REAL data-parallel engine path with world_size 2 on the one GPU of the box.
+
+Two fresh child processes share cuda:0 and form a gloo process group over CUDA tensors; each builds the model from a
+DIFFERENT seed and drives `engine.TrainStep(group=...)` on its shard of a global batch for three optimizer steps.  That
+executes, in the product code and with world > 1: FlatParams.broadcast (rank 0's parameters win), the per-step flat
+gradient all-reduce between backward and optimizer, grad_scale = 1/world inside the fused Adam kernel, and the per-rank
+noise generators (seed + rank).  The parent then runs ONE process on the whole batch with the same noise and compares.
+RCCL itself needs one GPU per rank and is the driver's to run (SCALE_rNN.json); everything above it is covered here.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT, TINY_CFG
+
+pytestmark = pytest.mark.gpu
+G, WORLD, STEPS, SEED = 8, 2, 3, 666
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(G, 162, 3, generator=g)
+    y = torch.nn.functional.one_hot(torch.arange(G) % 2, 2)
+    return x, y
+
+
+def _net(dev, seed, dropout):
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_tiny.npz"), dev)
+    torch.manual_seed(seed)
+    return cheb_VAE(3, dict(TINY_CFG, dropout=dropout), D, U, A, nn_).to(dev).train()
+
+
+def _worker(rank, world, port, out_dir, dropout, overlap):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from meshvae_hip.engine import TrainStep, shard_range
+    net = _net(dev, SEED + 17 * rank, dropout)              # replicas must NOT rely on equal seeds
+    lo, hi = shard_range(G, rank, world)
+    step = TrainStep(net, hi - lo, lr=1e-3, weight_decay=5e-4, use_graph=False, group=dist.group.WORLD, noise_seed=SEED,
+                     overlap_allreduce=overlap)
+    assert step.world == world
+    x, y = _data()
+    step.load(x[lo:hi].to(dev), x[lo:hi].to(dev), y[lo:hi].to(dev))
+    losses = []
+    for _ in range(STEPS):
+        loss, correct, recon = step.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    torch.save({"param": step.flat.param.cpu(), "grad": step.flat.grad.cpu(), "losses": losses,
+                "adam_steps": int(step.opt.step_count)}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_trainstep_world2_on_one_gpu_equals_the_single_process_step(tmp_path, overlap):
+    """dropout 0 (the reparameterisation noise is the only randomness, and the parent can rebuild it: rank r draws
+    from Generator(seed + r)): three steps on two shards of 4 == three steps of one process on all 8 meshes."""
+    port = _free_port()
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), 0.0, overlap), nprocs=WORLD, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(WORLD))
+    assert torch.equal(r0["param"], r1["param"])           # replicas agree bitwise after three all-reduced steps
+    assert torch.equal(r0["grad"], r1["grad"])             # ... on the reduced gradient too
+    assert r0["adam_steps"] == r1["adam_steps"] == STEPS
+    assert r0["losses"] != r1["losses"]                    # (different shards, different noise)
+    from meshvae_hip.engine import TrainStep
+    dev = torch.device("cuda:0")
+    net = _net(dev, SEED, 0.0)                             # rank 0's initial parameters (its seed)
+    big = TrainStep(net, G, lr=1e-3, weight_decay=5e-4, use_graph=False)
+    x, y = _data()
+    big.load(x.to(dev), x.to(dev), y.to(dev))
+    gens = [torch.Generator().manual_seed(SEED + r) for r in range(WORLD)]
+    Z = net.z
+
+    def eps_of_all_ranks():                                # what the two ranks drew for their shards, in shard order
+        big.eps.copy_(torch.cat([torch.normal(mean=0, std=1, size=(G // WORLD, Z), generator=g) for g in gens]))
+    big._draw_eps = eps_of_all_ranks
+    losses = [float(big.step()[0]) for _ in range(STEPS)]
+    torch.cuda.synchronize()
+    # the single-process loss is the mean over 8 meshes = the mean of the two ranks' means over 4
+    for k in range(STEPS):
+        assert abs(losses[k] - 0.5 * (r0["losses"][k] + r1["losses"][k])) <= 2e-6 * abs(losses[k]) + 1e-3
+    torch.testing.assert_close(r0["param"], big.flat.param.cpu(), rtol=1e-4, atol=2e-6)
+    assert losses[-1] < losses[0]
+
+
+def test_trainstep_world2_with_dropout_keeps_replicas_identical(tmp_path):
+    """dropout 0.2: every rank draws its own masks (device generator seeded seed + rank); the replicas must still hold
+    bitwise identical parameters after every all-reduced step, and the loss must fall."""
+    port = _free_port()
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), 0.2, False), nprocs=WORLD, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(WORLD))
+    assert torch.equal(r0["param"], r1["param"]) and torch.isfinite(r0["param"]).all()
+    assert all(l == l for l in r0["losses"] + r1["losses"])
