@@ -412,6 +412,37 @@ def run_infer(args, dev, emit):
     emit(out)
 
 
+def timed_variant(dev, config, dtype, B, steps, warmup, prewarm, seed):
+    """One more driver-timed train configuration with the main leg's protocol (same TrainStep, synthetic batch resident
+    in HBM, W untimed + K timed steps between device synchronisations) -> the figures of its own bench line."""
+    from meshvae_hip.engine import TrainStep
+    net = build_model(dev, config).train()
+    step = TrainStep(net, B, lr=1e-3, weight_decay=5e-4, use_graph=False, m_type="train", noise_seed=seed, storage=dtype)
+    x = torch.randn(B, net.num_nodes[0], 3, generator=torch.Generator().manual_seed(0))
+    step.x.copy_(x)
+    step.x_gt = x.double().to(dev)
+    step.y.copy_(torch.nn.functional.one_hot(torch.arange(B) % 2, 2))
+    for i in range(prewarm + warmup):
+        step.step()
+        if i % 50 == 49:
+            torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    loss = float(step.out[0])
+    assert np.isfinite(loss), f"non-finite loss in the {config}/{dtype} variant"
+    mps = B * steps / dt
+    bpm = ALGO_BYTES_PER_MESH[(config, dtype)]
+    return {"workload": WORKLOADS[config] + f", {B} meshes/GPU, {dtype} storage", "value": mps, "unit": "meshes/s",
+            "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "prewarm_steps": prewarm, "dtype": dtype,
+            "final_loss": loss,
+            "step_roofline": {"bound": "hbm", "achieved": mps * bpm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": mps * bpm / 1e9 / HBM_PEAK_GBS, "note": f"meshes/s x {bpm / 1e6:.2f} MB/mesh (SURVEY 8(d))"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,6 +468,8 @@ def main():
     ap.add_argument("--seed", type=int, default=666, help="weights: this seed on every rank; noise: seed + rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra driver-timed legs of the default line (bf16 storage; the 20k configuration)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (rank 0's JSON): libraries that print there (RCCL writes a five-line version
@@ -539,6 +572,15 @@ def main():
             out["roofline"], out["kernels"] = kernel_roofline(net, B, dev, args.config, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, B if args.config == "train5k" else 4)
+        if world == 1 and args.config == "train5k" and args.dtype == "f32" and not args.no_variants and not step.use_graph:
+            # the other BASELINE configurations this library runs, timed by the same process with the same protocol AFTER
+            # the headline's timed region (they never touch `value`): configs[1] as worded (bf16 storage), configs[3]
+            del step
+            torch.cuda.empty_cache()
+            out["variants"] = {
+                "bf16": timed_variant(dev, "train5k", "bf16", B, args.steps, args.warmup, min(prewarm, 100), args.seed),
+                "hires20k": timed_variant(dev, "hires20k", "f32", B, max(10, args.steps // 2), max(3, args.warmup // 2), 20,
+                                          args.seed)}
         emit(out)
     if dist.is_initialized():
         dist.barrier()

@@ -620,6 +620,13 @@ def test_bench_line_contract():
     assert d["config"]["workload"].startswith("configs[1]")
     assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert len(d["kernels"]) == 25                       # 9 conv layers x (fwd, dX, dW) minus the first layer's dX and dW
+    # the other configurations, driver-timed by the same process after the headline's timed region
+    v = d["variants"]
+    assert set(v) == {"bf16", "hires20k"}
+    assert v["bf16"]["dtype"] == "bf16" and v["bf16"]["workload"].startswith("configs[1]") and v["bf16"]["steps"] == 5
+    assert v["hires20k"]["workload"].startswith("configs[3]") and v["hires20k"]["value"] > 0
+    for leg in v.values():
+        assert abs(leg["value"] - 64 * 1e3 / leg["ms_per_step"]) < 1e-6 * leg["value"] and 0 < leg["step_roofline"]["frac"] < 1
 
 
 def test_bench_infer_line_contract():

@@ -4,7 +4,7 @@
 TAG="$1"; shift
 export TMPDIR=/tmp
 OUT="gpurun_out/ks_$TAG"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o s -- python3 bench.py --steps 50 --warmup 10 --prewarm-steps 0 --no-cpu-baseline --no-kernel-roofline "$@" > "gpurun_out/${TAG}_kstats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o s -- python3 bench.py --steps 50 --warmup 10 --prewarm-steps 0 --no-cpu-baseline --no-kernel-roofline --no-variants "$@" > "gpurun_out/${TAG}_kstats.log" 2>&1
 f=$(find "$OUT" -name "s_kernel_stats.csv" | head -1)
 python - "$f" > "gpurun_out/${TAG}_kstats.txt" <<'PY'
 import csv, sys

@@ -21,8 +21,8 @@ export TMPDIR=/tmp
 BENCH_ARGS="$@"
 python bench.py --steps 100 --warmup 20 $BENCH_ARGS > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "bench done: $(cut -c1-200 $OUT/bench_n1.json)"
-SHORT="--steps 20 --warmup 3 --prewarm-steps 0 --no-cpu-baseline --no-kernel-roofline $BENCH_ARGS"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 100 --warmup 20 --prewarm-steps 100 --no-cpu-baseline --no-kernel-roofline $BENCH_ARGS > "$OUT/stats.log" 2>&1
+SHORT="--steps 20 --warmup 3 --prewarm-steps 0 --no-cpu-baseline --no-kernel-roofline --no-variants $BENCH_ARGS"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 bench.py --steps 100 --warmup 20 --prewarm-steps 100 --no-cpu-baseline --no-kernel-roofline --no-variants $BENCH_ARGS > "$OUT/stats.log" 2>&1
 echo "stats done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL"; do
   name=$(echo "$pass" | cut -d' ' -f1)
