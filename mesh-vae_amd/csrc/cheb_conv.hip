@@ -1301,22 +1301,27 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
       weff = split;
     }
     MVH_REQUIRE(!io.dout, "cheb_conv_bwd: the split path reads an fp32 output gradient");
-    if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act, io.dx)) return rc;
+    // (dx_lazy: the rows off the connected block are rebuilt by the consumer from dout and W_eff, ConvIO::src3_*)
+    if (!io.dx_lazy)
+      if (int rc = launch_gstack(st, dout, out, weff, dx, dx, rows, Cin, Cout, 1, act, io.dx)) return rc;
     bool handled = false;
     LdsConvOpts so;
     so.prepacked = prepacked_bwd; so.in_bs = N; so.out_bs = N; so.out_bf16 = io.dx;
     if (int rc = try_cheb_lds(st, lap_t->sub, dout, act == MVH_ACT_RELU ? out : nullptr, W, nullptr, dx, B,
                               lap_t->n_active, Cin, Cout, K, act, true, wpack, &handled, so)) return rc;
     dx_done = handled;
+    MVH_REQUIRE(handled || !io.dx_lazy, "cheb_conv_bwd: dx_lazy without the LDS kernel for the connected block");
   }
+  MVH_REQUIRE(!io.dx_lazy || dx_done || !dx, "cheb_conv_bwd: dx_lazy on a layer that is not on the split path");
   if (!dw_done && !tx_saved) {  // fused dW/db: recurrence in LDS, contraction over vertices on the matrix pipe
     const size_t pbytes = defer ? defer_bytes : (size_t)((char*)ws + ws_bytes - (char*)partial);
     if (int rc = try_cheb_dw_lds(st, lap, x, dout, act == MVH_ACT_RELU ? out : nullptr, dW, db, B, N, Cin, Cout, K,
                                  defer ? defer_part : partial, pbytes, &dw_done, 0, nullptr, 0, false, out_bits, defer,
-                                 io.x, io.dout))
+                                 io.x, io.dout, &io))
       return rc;
     if (defer && dw_done) *deferred = true;
   }
+  MVH_REQUIRE(!io.src3_g || dw_done, "cheb_conv_bwd: lazy output-gradient rows (src3) need the LDS-resident dW kernel");
   if (!dw_done && bf)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dW kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);
@@ -1341,6 +1346,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     bo.prepacked = prepacked_bwd;
     bo.mask_bits = out_bits;
     bo.in_bf16 = io.dout; bo.prepacked_h = io.wh;
+    bo.src3_g = io.src3_g; bo.src3_w = io.src3_w; bo.src3_n = io.src3_n; bo.src3_c = io.src3_c;
     if (dx_pool_t && dx_pooled) {  // pooled rows straight from the kernel (dx itself is not materialised)
       bo.out_pool_t = dx_pool_t;
       bo.out_bf16 = io.dx_pooled;
@@ -1358,6 +1364,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
       return MVH_OK;
     }
   }
+  MVH_REQUIRE(!io.src3_g, "cheb_conv_bwd: lazy output-gradient rows (src3) need the LDS-resident dX kernel");
   if (bf)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dX kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);

@@ -35,6 +35,7 @@ struct DwDims {
   int mask_bits;                           // the mask pointer holds ReLU sign bytes (one per vertex and 4 channels)
   int ovf;                                 // MVH_CSR_ELL_OVERFLOW: rows longer than 8 continue in the CSR columns
   int p_bf16, q_bf16;                      // the P / Q tensor is stored as bf16 (bf16.hpp); masks are sign bytes then
+  int src3_n, src3_c;                      // > 0: P rows >= src3_n are p_g3[v][0..src3_c) W3^T (ConvIO::src3_*; P = dout, fp32)
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(TCT > 0 ? TCT : 1024)
 k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, const float* __restrict__ p_Q,
               const float* __restrict__ p_Qmask, const uint32_t* __restrict__ p_rowinfo,
               const uint32_t* __restrict__ p_ell, float* __restrict__ p_part, const int32_t* __restrict__ p_map,
-              const int* __restrict__ p_col, DwDims a) {
+              const int* __restrict__ p_col, const float* __restrict__ p_g3, const float* __restrict__ p_w3, DwDims a) {
   // CQ % 8 == 0: the workgroup holds all CQ channels of Q (16 per float4-per-lane register group);
   // CQ == 4   : "Q-split" mode for P sides of <= 4 channels (cheb.0 and the final layer): the
   //             a.CQtot channels of Q are split over CQtot/4 workgroups (one channel per lane,
@@ -259,9 +260,10 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const bool slab_full = (s0 + 4 <= a.CP) && (a.CP % 4 == 0);
   // (as in cheb_lds.hip: the wave-uniform mode branches would fence each vertex's loads, so the loop is
   //  instantiated per mode -- 0 plain full slab, 1 fp32 mask, 2 sign bytes, 3 general (row map, partial slab))
-  auto load_p = [&](auto mode_tag, auto bf_tag) {
+  auto load_p = [&](auto mode_tag, auto bf_tag, auto src3_tag) {
     constexpr int kMode = decltype(mode_tag)::value;
     constexpr bool kBF = decltype(bf_tag)::value;
+    constexpr bool kSrc3 = decltype(src3_tag)::value;   // lazy P rows (ConvIO::src3_*): modes 0 / 2, fp32, full slab
   #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       const int v = tid + vi * THREADS;
@@ -301,7 +303,16 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
       }
       if (kMode != 3 || slab_full) {
         float4 tv;
-        if constexpr (kBF) tv = bf16_unpack4(*reinterpret_cast<const uint2*>(Ph + (long long)pl * a.CP + s0));
+        if constexpr (kSrc3) {
+          const float* gr = p_g3 + ((long long)mesh * N + vl) * 3;   // (src3_c == 3: host check)
+          const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+          float r4[4];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            r4[j] = fmaf(g2, p_w3[(s0 + j) * 3 + 2], fmaf(g1, p_w3[(s0 + j) * 3 + 1], g0 * p_w3[(s0 + j) * 3]));
+          tv = make_float4(r4[0], r4[1], r4[2], r4[3]);
+          if (vi == 0 && tid < a.src3_n) tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);   // stored rows
+        } else if constexpr (kBF) tv = bf16_unpack4(*reinterpret_cast<const uint2*>(Ph + (long long)pl * a.CP + s0));
         else tv = *reinterpret_cast<const float4*>(Pb + (long long)pl * a.CP + s0);
         if (!phave) tv = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((kMode == 1 || kMode == 3) && Pm) {
@@ -341,15 +352,24 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
     using T = std::true_type;
     using F = std::false_type;
     const int pm = (a.map_side == 1 || !slab_full) ? 3 : (Pbits ? 2 : (Pm ? 1 : 0));
-    if (pbf) {  // (bf16 rows never come with an fp32 mask: mode 1 does not exist for them)
-      if (pm == 3) load_p(std::integral_constant<int, 3>{}, T{});
-      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, T{});
-      else load_p(std::integral_constant<int, 0>{}, T{});
+    bool done = false;
+    if constexpr (CQ == 16 && TCT == 512) {
+      if (a.src3_n > 0) {  // (host: fp32 P = dout, full slabs, no row map, sign bytes or no mask)
+        if (pm == 2) load_p(std::integral_constant<int, 2>{}, F{}, T{});
+        else load_p(std::integral_constant<int, 0>{}, F{}, T{});
+        done = true;
+      }
+    }
+    if (done) {
+    } else if (pbf) {  // (bf16 rows never come with an fp32 mask: mode 1 does not exist for them)
+      if (pm == 3) load_p(std::integral_constant<int, 3>{}, T{}, F{});
+      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, T{}, F{});
+      else load_p(std::integral_constant<int, 0>{}, T{}, F{});
     } else {
-      if (pm == 3) load_p(std::integral_constant<int, 3>{}, F{});
-      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, F{});
-      else if (pm == 1) load_p(std::integral_constant<int, 1>{}, F{});
-      else load_p(std::integral_constant<int, 0>{}, F{});
+      if (pm == 3) load_p(std::integral_constant<int, 3>{}, F{}, F{});
+      else if (pm == 2) load_p(std::integral_constant<int, 2>{}, F{}, F{});
+      else if (pm == 1) load_p(std::integral_constant<int, 1>{}, F{}, F{});
+      else load_p(std::integral_constant<int, 0>{}, F{}, F{});
     }
   }
   if (a.db_mode == 2 && q0 == 0) {  // column sums of the P slab (dpre): every lane holds its own vertices' sum
@@ -600,25 +620,27 @@ int launch_dw_reduce_all(hipStream_t st, const DwReduceTable& t) {
 
 template <int CQ, int VPT, int TCT, int PW>
 static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
-                         const mvh_csr_t* lap, float* part, const DwDims& d, int threads, const int32_t* map) {
+                         const mvh_csr_t* lap, float* part, const DwDims& d, int threads, const int32_t* map,
+                         const float* g3, const float* w3) {
   auto kern = k_cheb_dw_lds<CQ, VPT, TCT, PW>;
   const size_t lds = (size_t)VPT * threads * (16 + PW * 4);
   static LdsAttr attr;
   if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
   const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, d);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, g3, w3, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
 
 template <int CQ>
 static int launch_dw_cq(hipStream_t st, const float* P, const float* Pm, const float* Q, const float* Qm,
-                        const mvh_csr_t* lap, float* part, const DwDims& d, int vpt, int threads, const int32_t* map) {
+                        const mvh_csr_t* lap, float* part, const DwDims& d, int vpt, int threads, const int32_t* map,
+                        const float* g3 = nullptr, const float* w3 = nullptr) {
   const bool pw8 = d.pairs > 4;
 #define MVH_DW(V, T)                                                                                         \
-  return pw8 ? launch_dw_one<CQ, V, T, 8>(st, P, Pm, Q, Qm, lap, part, d, threads, map)                      \
-             : launch_dw_one<CQ, V, T, 4>(st, P, Pm, Q, Qm, lap, part, d, threads, map)
+  return pw8 ? launch_dw_one<CQ, V, T, 8>(st, P, Pm, Q, Qm, lap, part, d, threads, map, g3, w3)              \
+             : launch_dw_one<CQ, V, T, 4>(st, P, Pm, Q, Qm, lap, part, d, threads, map, g3, w3)
   if (vpt == 1) { MVH_DW(1, 0); }
   if (vpt == 2) { MVH_DW(2, 0); }
   if constexpr (CQ <= 16) {
@@ -639,8 +661,9 @@ size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K) {
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
-                    const uint8_t* out_bits, DwReduceEntry* defer, bool x_bf16, bool dout_bf16) {
+                    const uint8_t* out_bits, DwReduceEntry* defer, bool x_bf16, bool dout_bf16, const ConvIO* src3) {
   *handled = false;
+  if (src3 && !src3->src3_g) src3 = nullptr;
   if (dbg().force_generic) return MVH_OK;
   if (x_bf16 && dout_bf16 && !dout_map && bstride == 0 && (out_bits || !out_mask)) {
     // the 5k level's 16 -> 16 layer on bf16 rows: packed registers, contraction on the bf16 matrix pipe
@@ -689,6 +712,14 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   d.map_bs = dout_rows;
   d.p_bf16 = (p_is_x ? x_bf16 : dout_bf16) ? 1 : 0;
   d.q_bf16 = (p_is_x ? dout_bf16 : x_bf16) ? 1 : 0;
+  d.src3_n = 0; d.src3_c = 0;
+  if (src3) {  // lazy dout rows: the 5k level's fp32 16 -> 16 kernel with the recurrence on dout only
+    const bool ok = !p_is_x && CQ == 16 && CP == 16 && vpt == 10 && threads == 512 && !dout_bf16 && !dout_map && bstride == 0 &&
+                    (!out_mask || out_bits) && src3->src3_w && src3->src3_c == 3 && src3->src3_n >= 1 &&
+                    src3->src3_n <= 512;
+    if (!ok) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: lazy output-gradient rows (src3) on a layer without that kernel");
+    d.src3_n = src3->src3_n; d.src3_c = src3->src3_c;
+  }
   const float* P = p_is_x ? x : dout;
   const float* Pm = p_is_x ? nullptr : out_mask;
   const float* Q = p_is_x ? dout : x;
@@ -696,7 +727,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   int rc;
   if (NS == 1 && CQ % 4 == 0 && CQ >= 8) rc = launch_dw_cq<4>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);  // Q-split
   else if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
-  else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
+  else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map, src3 ? src3->src3_g : nullptr,
+                                           src3 ? src3->src3_w : nullptr);
   else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
   if (rc) return rc;

@@ -52,6 +52,9 @@ struct LdsConvArgs {
   int pt_rows;
   int in_bf16, out_bf16, pooled_bf16;  // storage type of in / out / pooled: bf16 instead of fp32 (bf16.hpp)
   int out_dead;                        // forward + pool_inv: only the selected rows (and their sign bytes) are stored
+  const float* g3;                     // ConvIO::src3_*
+  const float* w3;
+  int src3_n, src3_c;
 };
 
 __device__ __forceinline__ void add4(float4& a, const float4& b) {
@@ -65,6 +68,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
 struct LdsConvDims {
   int B, N, K, CO, Cin, Cout, pairs, act, in_bs, out_bs, mask_bs, pooled_bs, mask_bits, pt_rows, ovf;
   int in_bf16, out_bf16, pooled_bf16, out_dead;
+  int src3_n, src3_c;   // > 0: input rows >= src3_n are p_g3[v][0..src3_c) W3^T (lazy output gradient of a split-path layer)
 };
 
 // Pointers are separate __restrict__ kernel arguments (not struct members) so that hipcc can
@@ -79,7 +83,7 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
            const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_in_map,
            const int32_t* __restrict__ p_pool_inv, float* __restrict__ p_pooled, uint8_t* __restrict__ p_bits_out,
            const int* __restrict__ p_pt_rowptr, const int* __restrict__ p_pt_col, const float* __restrict__ p_pt_val,
-           const int* __restrict__ p_col, LdsConvDims a) {
+           const int* __restrict__ p_col, const float* __restrict__ p_g3, const float* __restrict__ p_w3, LdsConvDims a) {
   const int THREADS = TCT > 0 ? TCT : (int)blockDim.x;
   const int VS = VPT * THREADS;  // vertex slots (> N)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -131,10 +135,13 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   // The row map and the mask mode are wave-uniform; as run-time branches they would fence every vertex's
   // loads into its own basic block (one memory round trip per vertex).  The loop is therefore a generic
   // lambda instantiated per (map, mask mode) and dispatched once, so each copy is straight-line code.
-  auto load_rows = [&](auto map_tag, auto mask_tag, auto bf_tag) {
+  auto load_rows = [&](auto map_tag, auto mask_tag, auto bf_tag, auto src3_tag) {
     constexpr bool kMap = decltype(map_tag)::value;
     constexpr int kMask = decltype(mask_tag)::value;  // 0 none, 1 fp32 mask, 2 sign bytes
     constexpr bool kBF = decltype(bf_tag)::value;     // input rows stored as bf16
+    // lazy rows (ConvIO::src3_*): row v >= src3_n is g3[v][0..src3_c) W3^T; the first src3_n rows (all owned by threads
+    // tid < src3_n at vi == 0) are stored rows.  5k-level dX kernel only (CQ == 16, 1024 x 5, fp32, sign bytes).
+    constexpr bool kSrc3 = decltype(src3_tag)::value;
   #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
       const int v = tid + vi * THREADS;
@@ -200,6 +207,21 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
   #pragma unroll
           for (int c = 0; c < CQ; c += 4)
             tv[c / 4] = bf16_unpack4(*reinterpret_cast<const uint2*>(inh + (long long)rl * CQ + c));
+        } else if constexpr (kSrc3) {
+          const float* gr = p_g3 + ((long long)mesh * N + vl) * 3;   // (src3_c == 3: host check)
+          const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+  #pragma unroll
+          for (int c = 0; c < CQ; c += 4) {
+            float r4[4];
+  #pragma unroll
+            for (int j = 0; j < 4; ++j)   // (wave-uniform weights at constant offsets: scalar loads)
+              r4[j] = fmaf(g2, p_w3[(c + j) * 3 + 2], fmaf(g1, p_w3[(c + j) * 3 + 1], g0 * p_w3[(c + j) * 3]));
+            tv[c / 4] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+          }
+          if (vi == 0 && tid < a.src3_n) {  // (one divergent block in the first wave: the connected block's stored rows)
+  #pragma unroll
+            for (int c = 0; c < CQ; c += 4) tv[c / 4] = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
+          }
         } else {
   #pragma unroll
           for (int c = 0; c < CQ; c += 4) tv[c / 4] = *reinterpret_cast<const float4*>(inb + (long long)rl * CQ + c);
@@ -245,26 +267,34 @@ k_cheb_lds(const float* __restrict__ p_in, const float* __restrict__ p_mask, con
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
     const int mm = use_bits ? 2 : (mkb ? 1 : 0);
+    bool done = false;
+    if constexpr (CQ == 16 && TCT == 1024 && BWD) {
+      if (a.src3_n > 0) {  // (the host admits this only with sign bytes or no mask, no row map, fp32 rows)
+        if (mm == 2) load_rows(F{}, M2{}, F{}, T{});
+        else load_rows(F{}, M0{}, F{}, T{});
+        done = true;
+      }
+    }
     if constexpr (CQ % 4 == 0) {
-      if (a.in_bf16) {  // (bf16 rows come with sign bytes or no mask: the host refuses an fp32 mask)
+      if (a.in_bf16 && !done) {  // (bf16 rows come with sign bytes or no mask: the host refuses an fp32 mask)
         if (p_in_map) {
-          if (mm == 2) load_rows(T{}, M2{}, T{});
-          else load_rows(T{}, M0{}, T{});
+          if (mm == 2) load_rows(T{}, M2{}, T{}, F{});
+          else load_rows(T{}, M0{}, T{}, F{});
         } else {
-          if (mm == 2) load_rows(F{}, M2{}, T{});
-          else load_rows(F{}, M0{}, T{});
+          if (mm == 2) load_rows(F{}, M2{}, T{}, F{});
+          else load_rows(F{}, M0{}, T{}, F{});
         }
       }
     }
-    if (CQ % 4 != 0 || !a.in_bf16) {
+    if ((CQ % 4 != 0 || !a.in_bf16) && !done) {
       if (p_in_map) {
-        if (mm == 2) load_rows(T{}, M2{}, F{});
-        else if (mm == 1) load_rows(T{}, M1{}, F{});
-        else load_rows(T{}, M0{}, F{});
+        if (mm == 2) load_rows(T{}, M2{}, F{}, F{});
+        else if (mm == 1) load_rows(T{}, M1{}, F{}, F{});
+        else load_rows(T{}, M0{}, F{}, F{});
       } else {
-        if (mm == 2) load_rows(F{}, M2{}, F{});
-        else if (mm == 1) load_rows(F{}, M1{}, F{});
-        else load_rows(F{}, M0{}, F{});
+        if (mm == 2) load_rows(F{}, M2{}, F{}, F{});
+        else if (mm == 1) load_rows(F{}, M1{}, F{}, F{});
+        else load_rows(F{}, M0{}, F{}, F{});
       }
     }
   }
@@ -612,9 +642,9 @@ static int launch_one(hipStream_t st, const LdsConvArgs& a, int threads) {
   const int NS = (a.CO + 3) / 4;
   const int grid = ((a.B + 7) / 8) * 8 * NS;
   LdsConvDims d{a.B, a.N, a.K, a.CO, a.Cin, a.Cout, a.pairs, a.act, a.in_bs, a.out_bs, a.mask_bs, a.pooled_bs,
-                a.mask_bits, a.pt_rows, a.ovf, a.in_bf16, a.out_bf16, a.pooled_bf16, a.out_dead};
+                a.mask_bits, a.pt_rows, a.ovf, a.in_bf16, a.out_bf16, a.pooled_bf16, a.out_dead, a.src3_n, a.src3_c};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a.in, a.mask, a.W, a.bias, a.out, a.rowinfo, a.ell,
-                     a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, a.col, d);
+                     a.in_map, a.pool_inv, a.pooled, a.bits_out, a.pt_rowptr, a.pt_col, a.pt_val, a.col, a.g3, a.w3, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -678,6 +708,14 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
   a.mask_bits = 0; a.bits_out = nullptr;
   a.in_bf16 = o.in_bf16 ? 1 : 0; a.out_bf16 = o.out_bf16 ? 1 : 0; a.pooled_bf16 = o.pooled_bf16 ? 1 : 0;
   a.out_dead = (o.out_dead && o.pool_inv && !bwd) ? 1 : 0;
+  a.g3 = nullptr; a.w3 = nullptr; a.src3_n = 0; a.src3_c = 0;
+  if (o.src3_g) {  // lazy input rows: the 5k level's fp32 dX kernel only -- anything else must not pretend
+    const bool ok = bwd && CQ == 16 && !dbg().l0_wide && N + 1 > 2048 && N + 1 <= 5120 && !o.in_bf16 && !o.in_map &&
+                    (o.in_bs == 0 || o.in_bs == N) && (!mask || o.mask_bits) && o.src3_w && o.src3_c == 3 &&
+                    o.src3_n >= 1 && o.src3_n <= 1024 && !(lap->flags & MVH_CSR_ELL_OVERFLOW);
+    if (!ok) return fail(MVH_ERR_UNSUPPORTED, "cheb_lds: lazy output-gradient rows (src3) on a layer without that kernel");
+    a.g3 = o.src3_g; a.w3 = o.src3_w; a.src3_n = o.src3_n; a.src3_c = o.src3_c;
+  }
   // bf16 rows are read / written in 4-channel words, and a ReLU mask comes as sign bytes (never the fp32 output)
   if (o.in_bf16 && (CQ % 4 != 0 || (mask && !o.mask_bits))) return MVH_OK;
   if ((o.out_bf16 || o.pooled_bf16) && CO % 4 != 0) return MVH_OK;
@@ -717,6 +755,11 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
     MVH_LAUNCH_CHECK();
   }
+  // (MEASURED, not kept -- round 3, history: cheb_l0f.hip: the bf16 kernel's layout in fp32 -- two slabs, no ELL image, one
+  //  barrier per order -- with the neighbour ids re-read from the L2-resident ELL table every order because 80 VGPRs of
+  //  fp32 rows leave no room for them: 6 .. 13 spilled VGPRs instead of 29 .. 119, but 58.2 us per forward launch against
+  //  42.8 with one id load in flight ahead and 76.7 with three: a global load inside the gather loop costs more than the
+  //  ELL image and the second barrier it replaces.)
   int rc = -1;
   if (CQ == 3) rc = launch_cq<3>(st, a, bwd, vpt, threads);
   else if (CQ == 8) rc = launch_cq<8>(st, a, bwd, vpt, threads);

@@ -114,6 +114,7 @@ struct DebugCfg {
   int prefetch_at = 0;     // encoder stage behind which the forward launches the armed first-layer stack (MEASURED 0..3: 553-555 us, no difference)
   int dw_tie_x = 0;        // LDS dW kernel, Cin == Cout: the recurrence runs on x and dout stays in registers (round 2's choice)
   int roctx = 0;           // 1: roctxRangePush / Pop around every layer of mvh_vae_forward / mvh_vae_backward (MVH_RANGE)
+  int no_src3 = 0;         // 1: the final layer's dX writes all rows of its input gradient (no lazy rows in the 5k level's dX / dW)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
@@ -172,6 +173,9 @@ struct LdsConvOpts {
   // `pooled` are then 2-byte tensors behind the float pointers; arithmetic and the LDS state stay fp32
   bool in_bf16 = false, out_bf16 = false, pooled_bf16 = false;
   bool out_dead = false;                   // with pool_inv: store only the selected rows (pooled) and their sign bytes
+  const float* src3_g = nullptr;           // backward: input rows >= src3_n are src3_g[v][0..src3_c) W^T (ConvIO::src3_*)
+  const float* src3_w = nullptr;
+  int src3_n = 0, src3_c = 0;
   const uint32_t* prepacked_h = nullptr;   // bf16 weight slabs of cheb_l0h.hip already built (launch_pack_all)
 };
 // level-0 16 -> 16 forward / dX on bf16 rows with the contraction on the matrix pipe (cheb_l0h.hip)
@@ -222,6 +226,17 @@ struct ConvIO {
   // zero off the selected rows) -- the LDS-resident kernel then stores the pooled rows and their sign bytes only (a
   // quarter of the epilogue's stores, 20 MB less HBM traffic at the 5k level); every other path ignores the hint
   bool out_dead = false;
+  // "lazy" output gradient of a mostly-isolated (split-path) layer, cheb_VAE.py:288: off its connected block the layer is
+  // the per-vertex map x W_eff, so its dX row is dout_row W_eff^T -- three numbers per vertex at the final layer.
+  //   dx_lazy (that layer's backward): write ONLY the connected block's rows of dx (no all-rows pass, no [B, N, Cin]
+  //   tensor streamed through HBM); the consumer below rebuilds the other rows while it loads them.
+  //   src3_* (the backward of the layer underneath, its dout = that dx): row v >= src3_n is src3_g[v][0..src3_c) W^T
+  //   with W = src3_w [C][src3_c] (W_eff), rows < src3_n are read from `dout` as stored.  LDS-resident fp32 kernels
+  //   of the 5k level only; a layer that cannot take the hint fails loudly (the step engine checks eligibility first).
+  bool dx_lazy = false;
+  const float* src3_g = nullptr;
+  const float* src3_w = nullptr;
+  int src3_n = 0, src3_c = 0;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
@@ -256,7 +271,8 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                                                                             compact buffer of dout_rows per mesh */,
                     bool dry_run = false, const uint8_t* out_bits = nullptr /* replaces out_mask when given */,
                     DwReduceEntry* defer = nullptr /* skip the reduce launch and describe it here instead */,
-                    bool x_bf16 = false, bool dout_bf16 = false /* storage type of x / dout (bf16.hpp) */);
+                    bool x_bf16 = false, bool dout_bf16 = false /* storage type of x / dout (bf16.hpp) */,
+                    const ConvIO* src3 = nullptr /* dout rows >= src3_n come from src3_g W^T (ConvIO::src3_*) */);
 
 // first-layer weight gradient through a saved Chebyshev stack (cheb_tstack.hip)
 size_t tstack_stack_floats(int B, int n_sel, int K);   // (n_sel = rows the pooling selects = pool->n_rows)

@@ -466,6 +466,15 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   int& ev = side->next_ev;  // ring shared by every chain on this device (record/wait pairs are adjacent)
   const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
                           d->down[0].n_rows == p.Nn[1] && !dbg().no_tstack;
+  // lazy rows between the final layer (split path, cheb_VAE.py:288) and the last decoder stage: the final layer's dX is
+  // dout W_eff^T off its 20-vertex block -- 3 numbers per vertex -- so it writes ONLY the block's rows and the stage's dX /
+  // dW kernels rebuild the other rows while they load them (no k_gstack_rows launch on the main chain, 64 -> 12 bytes
+  // per vertex read by each of the two chip-filling kernels, 20 MB less written).  5k-class fp32 models only.
+  const bool lazy3 = !bf && !dbg().no_src3 && !dbg().force_generic && !dbg().l0_wide && !dbg().dw_tie_x && !dbg().no_side &&
+                     p.Nn[0] + 1 > 2048 && p.Nn[0] + 1 <= 5120 && p.f[1] == 16 && p.f[2] == 16 && p.F0 == 3 &&
+                     d->lap[n].sub && d->lap[n].n_active >= 1 && d->lap[n].n_active <= 512 && d->lap_t[n].sub &&
+                     d->lap_t[n].n_active == d->lap[n].n_active && !(d->lap[0].flags & MVH_CSR_ELL_OVERFLOW) &&
+                     p.decBits[n - 1] != kNoBits && d->K[n - 1] >= 1;
   hipEvent_t ev_tstack = nullptr;
   const bool tail_on_main = use_tstack && sstream != main && dbg().tail_main != 0;
   DwReduceTable red;        // pending dW reductions: one launch after the join
@@ -561,6 +570,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     ConvIO io;
     io.x = bf; io.dx = bf;   // (g_recon is fp32)
     io.s_keep = F(p.s_final);
+    io.dx_lazy = lazy3;
     // (MEASURED, not kept: queueing this weight gradient BEHIND the last decoder stage's, so that the chip-filling
     //  level-0 dW starts as soon as this layer's dX has produced its dout -- 587 vs 583 us per fp32 step, 534 vs 523
     //  in bf16: started that early it takes the CUs from the level-0 dX kernel of the main chain)
@@ -577,6 +587,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     io.x = io.dout = io.dx = bf;
     io.dx_pooled = bf && i > 0;   // (stage 0 hands its pooled gradient to the fp32 dense head)
     if (i == n - 1 && p.pk_h_b != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_b));
+    if (i == n - 1 && lazy3) { io.src3_g = F(p.g_recon); io.src3_w = F(p.weff_final); io.src3_n = d->lap[n].n_active; io.src3_c = p.F0; }
     // dX and the upsampling backward (U^T) in one launch: the pooled gradient goes straight to the previous stage
     float* dst = (i > 0) ? F(p.g_decC[i - 1]) : F(p.g_d2);
     auto dx_this = [&]() -> int {
