@@ -307,8 +307,9 @@ def test_bf16_step_matrix_pipe_kernels_against_the_unpack_form():
     bf16 rows (debug switch no_l0h: unpack + fp32 v_fma on the fp32 weights).  Both store the same tensors in bf16 and
     use the step's fused pooling / un-pooling forms (in_map, out_pool_t with pooled_bf16, k_stack_dw with dout_bf16), so a
     wrong ReLU mask, a dropped order or a wrong pooled row in either family shows as an O(1) difference, while the
-    legitimate difference is the weight copy's rounding: 2^-9 per product term, incoherent.  Bars: recon 2e-3 of its
-    maximum, every gradient 2e-2 relative (measured figures are printed)."""
+    legitimate difference is the weight copy's rounding (2^-9 per product term, incoherent) and, after it, stored values
+    that fall on the other side of a bf16 rounding boundary (one bf16 ulp = 2^-8 of the value).  Bars: recon 8e-3 of its
+    maximum (measured 3.2e-3), every gradient 2e-2 relative (measured 5.2e-3)."""
     from meshvae_hip import debug_switch
     from meshvae_hip.engine import NativeStep
     dev = _dev()
@@ -338,4 +339,4 @@ def test_bf16_step_matrix_pipe_kernels_against_the_unpack_form():
     print(f"[bf16 mfma vs unpack] recon {e_recon:.2e} of max|recon|; worst gradient rel {worst:.2e} ({worst_k}); "
           f"loss {res['mfma'][2]:.3f} / {res['unpack'][2]:.3f}")
     assert not torch.equal(ra, rb)                       # two different kernel families really ran
-    assert e_recon < 2e-3 and worst < 2e-2, (e_recon, worst, worst_k)
+    assert e_recon < 8e-3 and worst < 2e-2, (e_recon, worst, worst_k)

@@ -236,6 +236,7 @@ def test_trainstep_graph_with_private_noise_replays_fresh_masks():
             step.capture(warmup=2)                 # consumes noise and touches params / Adam state: reset both
         from meshvae_hip.engine import rank_generators
         step.host_gen, step.dev_gen = rank_generators(3, 0, dev)
+        step._u_left = 0                           # (drop the uniforms drawn ahead with the old generator)
         step.flat.param.copy_(init)
         step.opt.exp_avg.zero_(), step.opt.exp_avg_sq.zero_(), step.opt.step_count.zero_()
         step.opt._host_step = None
