@@ -133,11 +133,27 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   auto load_q_fast = [&](auto bf_tag, auto bits_tag) {
     constexpr bool kBF = decltype(bf_tag)::value;
     constexpr bool kBits = decltype(bits_tag)::value;   // Q carries a ReLU mask as sign bytes (else: no mask at all)
+    // the degree of a step's vertex is the same for the 4 lanes of the vertex: lane i of the quad fetches the one of step
+    // s4 + i and the quad shares the four by DPP -- one row-info load per FOUR steps instead of one per step
+    static_assert(STEPS_CT % 4 == 0, "steps come in groups of four");
+    int deg4[STEPS_CT / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < STEPS_CT / 4; ++s4) {
+      const int vq = 16 * ((4 * s4 + (lane & 3)) * NW + wave) + (lane >> 2);
+      deg4[s4] = (int)(p_rowinfo[min(vq, N - 1)] & 255u);
+    }
 #pragma unroll
     for (int s = 0; s < STEPS_CT; ++s) {
       const int v = 16 * (s * NW + wave) + (lane >> 2);
       const int vl = min(v, N - 1);
-      const float deg = (float)(p_rowinfo[vl] & 255u);
+      int di;   // quad_perm [j, j, j, j] broadcast of lane j's value, j = s mod 4
+      switch (s & 3) {
+        case 0: di = __builtin_amdgcn_update_dpp(0, deg4[s >> 2], 0x00, 0xf, 0xf, false); break;
+        case 1: di = __builtin_amdgcn_update_dpp(0, deg4[s >> 2], 0x55, 0xf, 0xf, false); break;
+        case 2: di = __builtin_amdgcn_update_dpp(0, deg4[s >> 2], 0xAA, 0xf, 0xf, false); break;
+        default: di = __builtin_amdgcn_update_dpp(0, deg4[s >> 2], 0xFF, 0xf, 0xf, false); break;
+      }
+      const float deg = (float)di;
       float inv_s = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
       inv_s = (v < N) ? inv_s : 0.f;
       const float live = (v < N) ? 1.f : 0.f;
