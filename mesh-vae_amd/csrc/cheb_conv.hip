@@ -958,6 +958,8 @@ k_relu_bits(const float* __restrict__ out, uint8_t* __restrict__ bits, long long
   bits[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
 }
 
+static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
+bool mvh::conv_split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) { return split_eligible(lap, N, Cin, Cout, K); }
 static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   if (dbg().force_generic) return false;
   return lap->sub && lap->n_active > 0 && 4 * lap->n_active <= N && lap->sub->n_rows == lap->n_active &&
@@ -1027,7 +1029,8 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
       weff = wbuf;
     }
     MVH_REQUIRE(!io.out, "cheb_conv_fwd: the split path writes fp32 rows");
-    if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act, io.x)) return rc;
+    if (!io.out_lazy)
+      if (int rc = launch_contract(st, x, nullptr, weff, bias, out, rows, Cin, Cout, 1, act, io.x)) return rc;
     bool handled = false;
     LdsConvOpts so;
     so.prepacked = prepacked; so.in_bs = N; so.out_bs = N; so.in_bf16 = io.x;
@@ -1038,8 +1041,10 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
         if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true, io.pooled)) return rc;
       return finish(false);
     }  // otherwise fall through: the full path rewrites every row
+    MVH_REQUIRE(!io.out_lazy, "cheb_conv_fwd: out_lazy without the LDS kernel for the connected block");
     if (bf) return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: bf16 storage needs the LDS-resident kernel for the active block");
   }
+  MVH_REQUIRE(!io.out_lazy, "cheb_conv_fwd: out_lazy on a layer that is not on the split path");
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;

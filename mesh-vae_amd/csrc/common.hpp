@@ -115,6 +115,7 @@ struct DebugCfg {
   int dw_tie_x = 0;        // LDS dW kernel, Cin == Cout: the recurrence runs on x and dout stays in registers (round 2's choice)
   int roctx = 0;           // 1: roctxRangePush / Pop around every layer of mvh_vae_forward / mvh_vae_backward (MVH_RANGE)
   int no_src3 = 0;         // 1: the final layer's dX writes all rows of its input gradient (no lazy rows in the 5k level's dX / dW)
+  int no_final_fuse = 0;   // 1: the final layer's per-vertex map as its own launch (k_cheb_contract) instead of inside the loss launch
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
@@ -234,11 +235,15 @@ struct ConvIO {
   //   with W = src3_w [C][src3_c] (W_eff), rows < src3_n are read from `dout` as stored.  LDS-resident fp32 kernels
   //   of the 5k level only; a layer that cannot take the hint fails loudly (the step engine checks eligibility first).
   bool dx_lazy = false;
+  bool out_lazy = false;   // forward of a split-path layer: write ONLY the connected block's rows of `out` (the loss launch
+                           // rebuilds the others, loss_fwd_impl's fuse_* arguments)
   const float* src3_g = nullptr;
   const float* src3_w = nullptr;
   int src3_n = 0, src3_c = 0;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
+// does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?
+bool conv_split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
 // conv entry points with optional prepacked weights (the extern "C" functions pass nullptr)
 int cheb_conv_fwd_impl(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias,
                        float* out, float* tx_saved, int B, int N, int Cin, int Cout, int K, int act, void* ws,
@@ -288,7 +293,11 @@ int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, c
 int loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
                   const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss, void* rec,
                   float* kld, int64_t* correct, int B, int NV, int C, int Z, void* ws, size_t ws_bytes,
-                  float* d_recon, float* d_mu, float* d_logvar, float* d_yhat);
+                  float* d_recon, float* d_mu, float* d_logvar, float* d_yhat,
+                  // optional: the final layer's per-vertex map fused into the first loss launch (recon rows >= fuse_n_act
+                  // are computed as fuse_x16[v] fuse_weff and WRITTEN to fuse_recon == recon; the others are read)
+                  const float* fuse_x16 = nullptr, const float* fuse_weff = nullptr, float* fuse_recon = nullptr,
+                  int fuse_cin = 0, int fuse_c3 = 0, int fuse_n_act = 0);
 // mvh_vae_latent_fwd with an optional fused dec_lin: d1 = dropout(relu(cat[y, z] Wd^T + bd)) (drop_d: its uniforms, same
 // p), bit-identical to mvh_linear_fwd; *fused tells whether the kernel took it (else the caller launches the GEMM)
 int latent_fwd_impl(hipStream_t st, const float* h, const float* y, const float* drop_u, float p, const float* Wc,

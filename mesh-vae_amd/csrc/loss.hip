@@ -12,25 +12,57 @@ namespace mvh {
 
 constexpr int kLossSplit = 16;  // blocks per mesh for the reconstruction sum
 
-template <typename GT>
+// FUSE: the reconstruction itself is produced here (rows >= n_act of the final layer, cheb_VAE.py:288, are the per-vertex
+// map x16[v] W_eff: element (v, o) = sum_c x16[v][c] W_eff[c][o], the fma chain of k_cheb_contract in the same order, so
+// the values are bitwise the separate launch's; rows < n_act were written by the connected block's kernel before) --
+// the element -> thread map and the order of the fp64 sums are those of the plain kernel, so loss and rec are too.
+struct LossFuse {
+  const float* x16;    // [B][N][cin] input of the final layer
+  const float* weff;   // [cin][c3]
+  float* recon_w;      // the reconstruction, written for rows >= n_act
+  int cin, c3, n_act;
+};
+
+template <typename GT, bool FUSE>
 __global__ void __launch_bounds__(256)
 k_loss_partial(const float* __restrict__ recon, const GT* __restrict__ gt, double inv_sigma,
-               double* __restrict__ partial, int NV, float* __restrict__ d_recon, double inv_var_over_B) {
+               double* __restrict__ partial, int NV, float* __restrict__ d_recon, double inv_var_over_B, LossFuse f) {
   const int b = blockIdx.y, s = blockIdx.x;
   const long long base = (long long)b * NV;
   double acc = 0.0;
   for (int i = s * blockDim.x + threadIdx.x; i < NV; i += gridDim.x * blockDim.x) {
+    float rv;
+    if constexpr (FUSE) {
+      const int v = i / f.c3, o = i - v * f.c3;
+      if (v >= f.n_act) {
+        const float* xr = f.x16 + ((long long)b * (NV / f.c3) + v) * f.cin;
+        float a = 0.f;
+        for (int c4 = 0; c4 < f.cin; c4 += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(xr + c4);
+          a = fmaf(t.x, f.weff[(c4 + 0) * f.c3 + o], a);
+          a = fmaf(t.y, f.weff[(c4 + 1) * f.c3 + o], a);
+          a = fmaf(t.z, f.weff[(c4 + 2) * f.c3 + o], a);
+          a = fmaf(t.w, f.weff[(c4 + 3) * f.c3 + o], a);
+        }
+        rv = a;
+        f.recon_w[base + i] = a;
+      } else {
+        rv = recon[base + i];
+      }
+    } else {
+      rv = recon[base + i];
+    }
     double d;
     if constexpr (sizeof(GT) == 8) {
-      d = ((double)gt[base + i] - (double)recon[base + i]) * inv_sigma;
+      d = ((double)gt[base + i] - (double)rv) * inv_sigma;
     } else {  // fp32 path: the reference subtracts and divides in fp32
-      const float df = (gt[base + i] - recon[base + i]) / (float)(1.0 / inv_sigma);
+      const float df = (gt[base + i] - rv) / (float)(1.0 / inv_sigma);
       d = (double)df;
     }
     acc += 0.5 * d * d;
     // gradient seed for d_loss = 1 (what k_loss_bwd_recon would write): the step engine skips the
     // separate backward pass over recon / x_gt
-    if (d_recon) d_recon[base + i] = (float)(inv_var_over_B * ((double)recon[base + i] - (double)gt[base + i]));
+    if (d_recon) d_recon[base + i] = (float)(inv_var_over_B * ((double)rv - (double)gt[base + i]));
   }
   __shared__ double red[256];
   red[threadIdx.x] = acc;
@@ -212,8 +244,15 @@ extern "C" int mvh_vae_loss_fwd(mvh_stream_t stream, const float* recon, const v
 int mvh::loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt, int gt_f64, const float* mu,
                        const float* logvar, const float* y, const float* y_hat, float log_sigma, void* loss,
                        void* rec, float* kld, int64_t* correct, int B, int NV, int C, int Z, void* ws,
-                       size_t ws_bytes, float* d_recon, float* d_mu, float* d_logvar, float* d_yhat) {
+                       size_t ws_bytes, float* d_recon, float* d_mu, float* d_logvar, float* d_yhat,
+                       const float* fuse_x16, const float* fuse_weff, float* fuse_recon, int fuse_cin, int fuse_c3,
+                       int fuse_n_act) {
   MVH_REQUIRE(recon && x_gt && mu && logvar && y && y_hat && loss && rec && kld && correct, "loss_fwd: null tensor");
+  LossFuse lf{fuse_x16, fuse_weff, fuse_recon, fuse_cin, fuse_c3, fuse_n_act};
+  const bool fuse = fuse_x16 != nullptr;
+  MVH_REQUIRE(!fuse || (fuse_weff && fuse_recon == recon && fuse_cin % 4 == 0 && fuse_c3 >= 1 && NV % fuse_c3 == 0 &&
+                        fuse_n_act >= 0 && ((uintptr_t)fuse_x16 & 15) == 0),
+              "loss_fwd: bad fused final-layer arguments");
   MVH_REQUIRE(B > 0 && NV > 0 && C > 0 && Z > 0, "loss_fwd: bad sizes");
   MVH_REQUIRE(ws && ws_bytes >= (size_t)B * kLossSplit * sizeof(double), "loss_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -224,15 +263,23 @@ int mvh::loss_fwd_impl(hipStream_t stream, const float* recon, const void* x_gt,
   const double ivb = 1.0 / (sigma * sigma) / (double)B;
   MVH_REQUIRE(!d_mu || (d_logvar && d_yhat), "loss_fwd: incomplete gradient-seed outputs");
   if (gt_f64) {
-    hipLaunchKernelGGL((k_loss_partial<double>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const double*)x_gt,
-                       1.0 / sigma, partial, NV, d_recon, ivb);
+    if (fuse)
+      hipLaunchKernelGGL((k_loss_partial<double, true>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const double*)x_gt,
+                         1.0 / sigma, partial, NV, d_recon, ivb, lf);
+    else
+      hipLaunchKernelGGL((k_loss_partial<double, false>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const double*)x_gt,
+                         1.0 / sigma, partial, NV, d_recon, ivb, lf);
     MVH_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_loss_finish<double>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
                        elem_const, (double*)loss, (double*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit,
                        d_mu, d_logvar, d_yhat);
   } else {
-    hipLaunchKernelGGL((k_loss_partial<float>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const float*)x_gt,
-                       1.0 / sigma, partial, NV, d_recon, ivb);
+    if (fuse)
+      hipLaunchKernelGGL((k_loss_partial<float, true>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const float*)x_gt,
+                         1.0 / sigma, partial, NV, d_recon, ivb, lf);
+    else
+      hipLaunchKernelGGL((k_loss_partial<float, false>), dim3(kLossSplit, B), dim3(256), 0, st, recon, (const float*)x_gt,
+                         1.0 / sigma, partial, NV, d_recon, ivb, lf);
     MVH_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_loss_finish<float>), dim3(1), dim3(256), 0, st, partial, mu, logvar, y, y_hat,
                        elem_const, (float*)loss, (float*)rec, kld, (long long*)correct, B, NV, C, Z, kLossSplit,
