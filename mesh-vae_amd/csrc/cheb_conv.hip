@@ -959,7 +959,7 @@ k_relu_bits(const float* __restrict__ out, uint8_t* __restrict__ bits, long long
 }
 
 static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
-bool mvh::conv_split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) { return split_eligible(lap, N, Cin, Cout, K); }
+bool conv_split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) { return split_eligible(lap, N, Cin, Cout, K); }
 static bool split_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   if (dbg().force_generic) return false;
   return lap->sub && lap->n_active > 0 && 4 * lap->n_active <= N && lap->sub->n_rows == lap->n_active &&
