@@ -784,6 +784,12 @@ int try_cheb_lds(hipStream_t st, const mvh_csr_t* lap, const float* in, const fl
     hipLaunchKernelGGL(k_pack_w, dim3(cdiv(n_pack, 256)), dim3(256), 0, st, W, wpack, K, Cin, Cout, CQ, CO, bwd ? 1 : 0);
     MVH_LAUNCH_CHECK();
   }
+  // (MEASURED, not kept -- round 3, tools/scratch/cheb_l0m.hip.txt: this kernel with the contraction on the matrix pipe and the
+  //  weight slab [K][16][4] in the LDS slots nobody uses (rows N + 1 .. of the slab and of the ELL image), read four values at
+  //  a time: parity-green, 28 .. 34 spilled VGPRs, 49.3 us per forward launch against 42.3.  v_mfma_f32_4x4x1 is an 8-cycle
+  //  instruction that holds the SIMD's vector issue for its whole length (MI355X_MICROARCH: 8 of an MFMA's cycles), so 16 of
+  //  them per vertex and order cost the VALU exactly what the 64 v_fma cost (2 cycles each): nothing moves off the pipe that
+  //  binds this kernel (SQ_ACTIVE_INST_VALU 76 %).  The bf16 form wins because 4x4x4 does four times the work per issue.)
   // (MEASURED, not kept -- round 3, history: cheb_l0f.hip: the bf16 kernel's layout in fp32 -- two slabs, no ELL image, one
   //  barrier per order -- with the neighbour ids re-read from the L2-resident ELL table every order because 80 VGPRs of
   //  fp32 rows leave no room for them: 6 .. 13 spilled VGPRs instead of 29 .. 119, but 58.2 us per forward launch against
