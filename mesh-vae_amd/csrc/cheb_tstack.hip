@@ -7,13 +7,14 @@
 // therefore needs T_k(L) x only at those rows.  Two kernels:
 //   k_cheb_tstack : ONE workgroup per mesh runs the K-order recurrence on the (<= 4 channel) input in
 //                   the 160 KB LDS image of the other LDS kernels and stores T_k x of the SELECTED rows only,
-//                   as one plane per order: stack [B][K][n_sel + 1][4].  Which vertex a thread slot owns is free, so
-//                   slots 0 .. n_sel-1 own the selected vertices in pooled-row order (slot r = vertex D.col[r]) and
-//                   the remaining slots the un-selected ones (an in-kernel prefix sum over D's inverse map): the
-//                   stores are the first ceil(n_sel / THREADS) slots of every thread -- no divergent store, and a
-//                   wave stores 1 KB of consecutive bytes.  (Round 2 stored every vertex as [B][N+1][K][4]: each
-//                   lane's 16 bytes in a 96-byte-strided line of its own -- 122 MB of partial-line writes per launch
-//                   for the 7.7 MB k_stack_dw reads, 48.6 us; profiles/r02_h_pmc.json.)
+//                   as one plane per order: stack [B][K][n_sel + 1][4].  The stores are decoupled from the
+//                   thread-owns-vertex recurrence: once an order's slab is complete every thread copies three rows of
+//                   the pooled-row order out of LDS (slab[D.col[r]] * deg^1/2), so a wave stores 1 KB of consecutive
+//                   bytes and no store is divergent.  (Round 2 stored every vertex as [B][N+1][K][4]: each lane's 16
+//                   bytes in a 96-byte-strided line of its own -- 122 MB of partial-line writes per launch for the
+//                   7.7 MB k_stack_dw reads, 48.6 us.  The first form of this round let slots own the selected
+//                   vertices instead: same bytes, but the permuted ownership lost the conflict-aware ELL order -- LDS
+//                   conflict share 0.52, 34.4 us.)
 //                   64 workgroups: it leaves 3/4 of the chip to the small kernels of the main chain,
 //                   which is where the step engine schedules it.
 //   k_stack_dw    : streaming reduction  stack^T * (dout masked by the ReLU sign bytes)  over the
@@ -32,79 +33,55 @@ struct TstackDims {
 template <int VPT, int TCT, int PW>
 __global__ void __launch_bounds__(TCT)
 k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowinfo, const uint32_t* __restrict__ p_ell,
-              const int32_t* __restrict__ p_sel_inv, const int32_t* __restrict__ p_sel_col, float* __restrict__ p_stack,
-              TstackDims a) {
+              const int32_t* __restrict__ p_sel_col, float* __restrict__ p_stack, TstackDims a) {
   constexpr int THREADS = TCT, VS = VPT * THREADS;
   extern __shared__ __align__(16) unsigned char smem[];
   float4* slab = reinterpret_cast<float4*>(smem);     // [VS] scaled t~_k = D^-1/2 T_k x; rows >= N stay zero
   uint4* ellv = reinterpret_cast<uint4*>(slab + VS);  // [VS][PW/4]
-  const int mesh = blockIdx.x, tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
-
-  // ---- slot -> vertex: slots [0, n_sel) = the selected vertices in pooled-row order, [n_sel, N) = the others in
-  //      ascending order, slots >= N own the zero rows N .. VS-1.  The list of un-selected vertices is built in the
-  //      (not yet staged) ELL area: thread t counts them in its chunk [t VPT, (t + 1) VPT), block-wide exclusive scan.
-  uint16_t* rest = reinterpret_cast<uint16_t*>(ellv);          // [N - n_sel] un-selected vertex ids
-  int* wsum = reinterpret_cast<int*>(rest + VS);               // [THREADS / 64] per-wave totals
-  {
-    int flag[VPT], cnt = 0;
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const int v = tid * VPT + j;
-      flag[j] = (v < N && p_sel_inv[min(v, N - 1)] < 0) ? 1 : 0;
-      cnt += flag[j];
-    }
-    int inc = cnt;  // inclusive scan over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int base = inc - cnt;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-    for (int j = 0; j < VPT; ++j)
-      if (flag[j]) rest[base++] = (uint16_t)(tid * VPT + j);
-    __syncthreads();
-  }
-  int vid[VPT];
-#pragma unroll
-  for (int vi = 0; vi < VPT; ++vi) {
-    const int slot = tid + vi * THREADS;
-    vid[vi] = slot < a.n_sel ? p_sel_col[slot] : (slot < N ? (int)rest[slot - a.n_sel] : slot);
-  }
-  __syncthreads();  // the list has been read: the area becomes the ELL image
+  const int mesh = blockIdx.x, tid = threadIdx.x, N = a.N;
   {
     const unsigned pad = (unsigned)N | ((unsigned)N << 16);
     const uint4 pad4 = make_uint4(pad, pad, pad, pad);
     const uint4* src = reinterpret_cast<const uint4*>(p_ell);
     for (int i = tid; i < VS * (PW / 4); i += THREADS) ellv[i] = (i / (PW / 4) < N) ? src[i] : pad4;
   }
-  float ka2[VPT], inv_s[VPT];
+  float ka2[VPT];
   float4 R[VPT];
-  // plane k of this mesh: [n_sel][4]; slot r < n_sel stores row r (consecutive lanes -> consecutive 16 bytes)
-  // (every plane has one more row, n_sel: the slots past n_sel of the storing slot range write there -- unconditional
-  //  stores; a predicated store per vertex and order cost 186 spilled VGPRs)
-  constexpr int kStoreSlots = (1536 + THREADS - 1) / THREADS;   // slots of a thread that may own selected vertices: n_sel <= 1536 (host check)
+  // The recurrence keeps the thread-owns-vertex layout of the other LDS kernels (vertex = slot: the conflict-aware ELL
+  // order applies).  The STORES are decoupled from it: after an order's slab is complete, thread t copies the rows
+  // r = t + j THREADS (j < kStoreRows) of the pooled-row order out of LDS -- slab[D.col[r]] times that vertex's deg^1/2 --
+  // so a wave stores 1 KB of consecutive bytes of plane k and no store is divergent (three extra LDS reads per thread and
+  // order beside 80 gathers).  Rows past n_sel go to the spare row n_sel of the plane.
+  constexpr int kStoreRows = (1536 + THREADS - 1) / THREADS;   // n_sel <= 1536 (host check)
   const int prow = a.n_sel + 1;
   float4* const sbase = reinterpret_cast<float4*>(p_stack) + (long long)mesh * a.K * prow;
   const float* xb = p_x + (long long)mesh * N * a.Cin;
+  int sv[kStoreRows];
+  float sis[kStoreRows];
+#pragma unroll
+  for (int j = 0; j < kStoreRows; ++j) {
+    const int r = tid + j * THREADS;
+    sv[j] = p_sel_col[min(r, a.n_sel - 1)];
+    const float deg = (float)(p_rowinfo[sv[j]] & 255u);
+    sis[j] = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = (c < a.Cin) ? xb[(long long)sv[j] * a.Cin + min(c, a.Cin - 1)] : 0.f;
+    sbase[min(r, a.n_sel)] = make_float4(t[0], t[1], t[2], t[3]);   // plane 0: T_0 x = x
+  }
 #pragma unroll
   for (int vi = 0; vi < VPT; ++vi) {
-    const int v = vid[vi];
+    const int v = tid + vi * THREADS;
     const bool valid = v < N;
     const int vl = min(v, N - 1);
     const float deg = valid ? (float)(p_rowinfo[vl] & 255u) : 0.f;
     ka2[vi] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     const float s = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-    inv_s[vi] = deg > 0.f ? __builtin_amdgcn_sqrtf(deg) : 1.0f;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c)  // branch-free (clamped index, selected afterwards): the vertices' loads overlap
       t[c] = (c < a.Cin) ? xb[(long long)vl * a.Cin + min(c, a.Cin - 1)] : 0.f;
     if (!valid) t[0] = t[1] = t[2] = t[3] = 0.f;
-    if (vi < kStoreSlots) sbase[min(tid + vi * THREADS, a.n_sel)] = make_float4(t[0], t[1], t[2], t[3]);  // T_0 x = x
     slab[v] = make_float4(t[0] * s, t[1] * s, t[2] * s, t[3] * s);
     R[vi] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -139,7 +116,7 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     const float sc = (k == 1) ? 0.5f : 1.0f;  // T_1 = L T_0 ; T_k = 2 L T_{k-1} - T_{k-2}
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
-      const float4 g = gather(vid[vi]);
+      const float4 g = gather(tid + vi * THREADS);
       const float kk = ka2[vi] * sc;
       R[vi] = make_float4(fmaf(kk, g.x, -R[vi].x), fmaf(kk, g.y, -R[vi].y), fmaf(kk, g.z, -R[vi].z),
                           fmaf(kk, g.w, -R[vi].w));
@@ -147,16 +124,17 @@ k_cheb_tstack(const float* __restrict__ p_x, const uint32_t* __restrict__ p_rowi
     __syncthreads();  // every gather of t~_{k-1} is done
 #pragma unroll
     for (int vi = 0; vi < VPT; ++vi) {
-      const int v = vid[vi];
+      const int v = tid + vi * THREADS;
       const float4 old = slab[v];
-      const float4 cur = R[vi];
-      slab[v] = cur;
+      slab[v] = R[vi];
       R[vi] = old;
-      if (vi < kStoreSlots)
-        sbase[(long long)k * prow + min(tid + vi * THREADS, a.n_sel)] =
-            make_float4(cur.x * inv_s[vi], cur.y * inv_s[vi], cur.z * inv_s[vi], cur.w * inv_s[vi]);
     }
-    __syncthreads();
+    __syncthreads();  // the slab holds t~_k (the next swap is two barriers away: the copies below are safe)
+#pragma unroll
+    for (int j = 0; j < kStoreRows; ++j) {
+      const float4 t = slab[sv[j]];
+      sbase[(long long)k * prow + min(tid + j * THREADS, a.n_sel)] = make_float4(t.x * sis[j], t.y * sis[j], t.z * sis[j], t.w * sis[j]);
+    }
   }
 }
 
@@ -282,7 +260,7 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
   auto kern = wide ? k_cheb_tstack<10, 512, 4> : k_cheb_tstack<5, 1024, 4>;
   static LdsAttr attr[2];   // (one per kernel)
   if (int rc = attr[wide ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
-  hipLaunchKernelGGL(kern, dim3(B), dim3(wide ? 512 : 1024), lds, st, x, lap->rowinfo, lap->ell, pool->sel_inv, pool->col, stack, d);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(wide ? 512 : 1024), lds, st, x, lap->rowinfo, lap->ell, pool->col, stack, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
