@@ -108,6 +108,9 @@ def lib():
             raise MeshVaeHipError(
                 f"{LIB_PATH} is missing: build it with `make -C mesh-vae_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch first: its wheel bundles its own libamdhip64; if this library were loaded before torch, the loader would
+        # bind it to /opt/rocm's copy and the process would hold two HIP runtimes (the second one sees no device)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
