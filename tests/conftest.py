@@ -14,6 +14,13 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs on torch's intra-op pool: a GPU box shows all 256 hardware threads of its host but a job's share
+    # is 16 cores -- unbounded, the B = 64 oracle passes took 3x longer (149 s instead of 44 s for the 20k model)
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 16))
+    except Exception:
+        pass
 
 
 def load_golden(name):

@@ -75,6 +75,7 @@ def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat, dtype=torch.float32
     decision of that site by the given mask (see _relu_ties)."""
     from oracle import cheb_oracle as O
     B = x.shape[0]
+    torch.set_num_threads(min(16, os.cpu_count() or 16))    # (the GPU box shares its host: 16 cores per GPU)
 
     class Recording(O.OracleVAE):
         def _relu(self, site, t):
@@ -237,8 +238,9 @@ def test_b64_hires20k_step_matches_oracle_on_all_meshes():
     pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k", "topology_20k.npz")
     if pins:
         want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
-    truth = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, dtype=torch.float64, pins=pins)
-    _compare_with_oracle(got, want, "b64 fp32 20k", truth=truth)
+    # (the float64 run beside it -- this library ~1e-5, the reference's fp32 1-2e-6 from the exact answer at this size --
+    #  is printed by the 5k test; here it would add a third 20k oracle pass to a test that already takes two minutes)
+    _compare_with_oracle(got, want, "b64 fp32 20k")
 
 
 @pytest.mark.parametrize("which", ["5k", "20k"])
