@@ -638,3 +638,47 @@ def test_bench_infer_line_contract():
     assert set(d["latency_ms"]) == {"b1", "b32", "b256"} and d["value"] == d["latency_ms"]["b32"]
     assert all(0.0 < v < 50.0 for v in d["latency_ms"].values())
     assert d["config"]["hipgraph"] is True and d["config"]["replay_equals_eager_bitwise"] is True
+
+
+@pytest.mark.parametrize("B", [5, 16])
+def test_round3_forms_against_their_debug_switches(B):
+    """Every form this round added to the native step has a debug switch that restores the previous launch sequence; the
+    step must not care: storing only what is read (keep_enc_out), the final layer's map inside the loss launch
+    (no_final_fuse) and the stack kernel's shape (tstack_tall) change NOTHING, bit for bit; lazy rows between the final
+    layer and the last decoder stage (no_src3) and the side the weight-gradient recurrence runs on (dw_tie_x) re-order
+    fp32 sums: gradients within 2e-5 relative, forward outputs bitwise."""
+    from conftest import CFG_5K
+    from meshvae_hip import debug_switch
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_5k.npz"), dev)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, nn_[0], 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+
+    def run(switch):
+        torch.manual_seed(666)
+        net = cheb_VAE(3, dict(CFG_5K), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
+        key, val = switch if switch else ("keep_enc_out", 0)
+        with debug_switch(key, val):
+            nat = NativeStep(net, B)
+            drop_u = torch.rand(B * nat.u_cols, generator=torch.Generator().manual_seed(9)).to(dev)
+            loss, corr, recon, (kld, rec, z_), yh = nat.forward_backward(x, x.double(), y, eps=eps, drop_u=drop_u)
+            torch.cuda.synchronize()
+        return (dict(loss=loss.clone(), recon=recon.clone(), kld=kld.clone(), rec=rec.clone(), z=z_.clone(), yh=yh.clone()),
+                {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    base_out, base_g = run(None)
+    for switch, exact in ((("keep_enc_out", 1), True), (("no_final_fuse", 1), True), (("tstack_tall", 1), True),
+                          (("no_src3", 1), False), (("dw_tie_x", 1), False)):
+        out, grads = run(switch)
+        for k in base_out:
+            assert torch.equal(out[k], base_out[k]), (switch, k)
+        for k in base_g:
+            if exact:
+                assert torch.equal(grads[k], base_g[k]), (switch, k)
+            else:
+                den = float(base_g[k].norm())
+                assert den == 0.0 or float((grads[k] - base_g[k]).norm()) / den < 2e-5, (switch, k)
