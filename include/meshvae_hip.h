@@ -98,7 +98,7 @@ int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
  * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch,
  * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse, no_big, no_dx_tstack,
  * no_dx_first, no_bwd_fused, no_dw_rows, keep_enc_out, dw_lane2, tstack_tall,
- * prefetch_at, dw_tie_x, no_src3, no_final_fuse, roctx (roctx ranges per layer of the step for rocprofv3 --marker-trace).  mvh_debug_set changes one switch in-process (the tests run
+ * prefetch_at, dw_tie_x, no_src3, no_final_fuse, skip_conv_dw (timing only: results invalid), roctx (roctx ranges per layer of the step for rocprofv3 --marker-trace).  mvh_debug_set changes one switch in-process (the tests run
  * both kernel families that way); mvh_debug_get returns its value, -1 for an unknown key. */
 int mvh_debug_set(const char* key, int32_t value);
 int32_t mvh_debug_get(const char* key);

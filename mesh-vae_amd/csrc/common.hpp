@@ -116,6 +116,7 @@ struct DebugCfg {
   int roctx = 0;           // 1: roctxRangePush / Pop around every layer of mvh_vae_forward / mvh_vae_backward (MVH_RANGE)
   int no_src3 = 0;         // 1: the final layer's dX writes all rows of its input gradient (no lazy rows in the 5k level's dX / dW)
   int no_final_fuse = 0;   // 1: the final layer's per-vertex map as its own launch (k_cheb_contract) instead of inside the loss launch
+  int skip_conv_dw = 0;    // TIMING ONLY, results invalid: no conv weight-gradient launches on the side lane (how long is the main chain alone?)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();

@@ -551,6 +551,12 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                           int K, int act, const uint8_t* bits, const ConvIO& io, size_t part_off = kNoBits,
                           size_t part_bytes = 0, const mvh_csr_t* dout_pool = nullptr, const mvh_csr_t* unpool_t = nullptr,
                           float* unpooled = nullptr, const float* tx = nullptr) -> int {
+    // TIMING ONLY (results invalid): 1 = the main chain without the weight-gradient lane; 2 = without the levels of <= 400
+    // vertices; 3 = without the 5k level's; 4 = without the levels of 401 .. 2047 vertices
+    {
+      const int sk = dbg().skip_conv_dw;
+      if (sk == 1 || (sk == 2 && N <= 400) || (sk == 3 && N > 2047) || (sk == 4 && N > 400 && N <= 2047)) return MVH_OK;
+    }
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
                                      dout_pool, unpool_t, unpooled, tx, io};
     if (n_pending >= fork_batch) return flush_dw(false);
