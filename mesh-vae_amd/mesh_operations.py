@@ -3,36 +3,142 @@ SURVEY section 8(f) "next" #1), host side, run once per template.
 
 Same entry points and return values as the reference module (`generate_transform_matrices(mesh, factors)
 -> (M, A, D, U)` with scipy COO matrices in the entry order model.py:24-32 turns into torch sparse
-tensors), written from the algorithm, not from its code:
+tensors).  The loops over mesh elements run in C++ (mesh-vae_amd/csrc/host/hierarchy.cpp ->
+libmeshvae_host.so, C ABI include/meshvae_host.h, bound below with ctypes):
 
 * adjacency A     : symmetric vertex-vertex incidence accumulated over the three face edges
-                    (:13-31), CSC -> COO (column-major entry order; the values count shared faces);
+                    (:13-31), CSC -> COO (column-major entry order; the values count shared faces) -- scipy;
 * decimation  D   : Garland-Heckbert quadric edge collapse restricted to vertex pairs (QSlim-style,
-                    :87-199): per-vertex quadrics from the faces' normalised plane equations (:45-70,
-                    plane = null vector of [v | 1] by SVD), a min-heap of edges keyed by
-                    min(q_sum(v_r), q_sum(v_c)), lazy re-evaluation of stale costs (:152-156),
-                    collapse onto the cheaper endpoint without moving it (:161-166), both
-                    endpoints inherit the summed quadric (:180-181), degenerate faces dropped, until
-                    ceil(n * factor) vertices are left; D is the one-hot selection of the surviving
-                    vertices in ascending index order (:72-85);
-* upsampling  U   : every fine vertex expressed in its closest coarse triangle (:202-250): closest
-                    point on the coarse surface, then barycentric-style weights by least squares on the
-                    triangle's / edge's vertex positions (a vertex hit gets weight 1).
+                    :87-199).  Face planes: the null vector of [v | 1] by np.linalg.svd, face by face, the
+                    reference's own LAPACK call (:58-61) -- on coplanar neighbourhoods (a subdivided template)
+                    the collapse order hangs on its last bits.  Everything after that is C++:
+                    `mvhh_vertex_quadrics` (face-major accumulation of p p^T), `mvhh_unique_edges` (the queue
+                    order), `mvhh_qslim_decimate` (CPython-heapq-compatible heap of mutable edge records, lazy
+                    re-evaluation of stale costs, collapse onto the cheaper endpoint, summed quadrics, degenerate
+                    faces dropped) until ceil(n * factor) vertices are left; D is the one-hot selection of the
+                    surviving vertices in ascending index order (:72-85);
+* upsampling  U   : every fine vertex expressed in its closest coarse triangle (:202-250): closest point by
+                    `mvhh_closest_points` (bounding-volume hierarchy over the triangles, exact with respect to the
+                    all-triangles scan), then barycentric-style weights by np.linalg.lstsq on the triangle's /
+                    edge's vertex positions (:229-243, the reference's LAPACK call; a vertex hit gets weight 1).
 
-What is done differently from the reference (results are bit-identical on the fixtures, tests/
-test_mesh_operations.py): the heap holds small mutable edge records that every live endpoint
-indexes, so renaming a collapsed vertex touches only its own edges instead of scanning the whole
-queue twice per collapse (:170-175 is O(|queue|) per collapse: 21 s at 5k vertices, minutes at
-20k); faces carry a live mask and per-vertex use counts instead of being re-filtered and
-re-uniqued per collapse; the closest-point search
-is a chunked, vectorised brute force (the reference uses psbody's AABB tree, which this image
-lacks; oracle/refshim has the same search for the fixture generator).
+Measured (8 host cores of the build container; tests/test_mesh_operations.py prints them): 5k template, four
+levels 21 s (reference) -> 0.5 s; 20k template, five levels: minutes -> 2 s.  Results are bit-identical to the
+reference's generator on the tiny / torus-5k / template-5k / subdivided-20k fixtures (A and D with entry
+order, U to 1e-6 of the stand-in closest-point search the fixtures were made with).  There is no numpy
+fall-back: without libmeshvae_host.so the calls raise.  The numpy restatement that used to live here is
+oracle/hierarchy_oracle.py, the checker of the tests.
 """
-import heapq
+import ctypes
 import math
+import os
 
 import numpy as np
 import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.environ.get("MESHVAE_HOST_LIB") or os.path.join(_HERE, "meshvae_hip", "libmeshvae_host.so")
+HOST_ABI_VERSION = 100   # MVHH_ABI_VERSION of include/meshvae_host.h this binding was written against
+_lib = None
+
+_D = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_L = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_PL = ctypes.POINTER(ctypes.c_int64)
+_I64 = ctypes.c_int64
+
+# name -> (restype, argtypes): every symbol of include/meshvae_host.h (tests/test_host_cpu.py checks the list)
+HOST_SIGNATURES = {
+    "mvhh_version": (ctypes.c_int32, []),
+    "mvhh_unique_edges": (ctypes.c_int32, [_L, _I64, _I64, _L, _PL]),
+    "mvhh_vertex_quadrics": (ctypes.c_int32, [_D, _L, _I64, _I64, _D]),
+    "mvhh_qslim_decimate": (ctypes.c_int32, [_D, _I64, _L, _I64, _D, _L, _I64, _I64, _L, _PL, _PL, ctypes.c_void_p]),
+    "mvhh_closest_points": (ctypes.c_int32, [_D, _I64, _L, _I64, _D, _I64, ctypes.c_int32, _L, _L, _D]),
+}
+
+
+class MeshVaeHostError(RuntimeError):
+    pass
+
+
+class BlasHooks(ctypes.Structure):
+    """mvhh_blas_t"""
+    _fields_ = [("cblas_dgemv", ctypes.c_void_p), ("cblas_ddot", ctypes.c_void_p), ("ilp64", ctypes.c_int32)]
+
+
+_blas = False   # False = not looked for yet, None = not found
+
+
+def numpy_cblas():
+    """The cblas_dgemv / cblas_ddot of the BLAS this process's numpy is linked to, as an mvhh_blas_t (or None).
+
+    The reference's pair cost IS two numpy dots (mesh_operations.py:121-122); handing the decimator the very entry
+    points numpy dispatches them to makes its costs -- and with them the collapse direction of exactly tied pairs --
+    those of the reference run on this machine.  Found through threadpoolctl (the loaded library's path); set
+    MESHVAE_HOST_PLAIN_COST=1 to use the library's built-in evaluation order instead."""
+    global _blas
+    if _blas is False:
+        _blas = None
+        if os.environ.get("MESHVAE_HOST_PLAIN_COST", "0") not in ("", "0"):
+            return _blas
+        try:
+            from threadpoolctl import threadpool_info
+            np.dot(np.ones((1, 2)), np.ones((2, 2)))            # (makes sure the BLAS is loaded)
+            for info in threadpool_info():
+                if info.get("user_api") != "blas":
+                    continue
+                handle = ctypes.CDLL(info["filepath"])
+                for pre, suf, ilp64 in (("scipy_", "64_", 1), ("", "64_", 1), ("scipy_", "", 0), ("", "", 0)):
+                    try:
+                        gemv = getattr(handle, f"{pre}cblas_dgemv{suf}")
+                        dot = getattr(handle, f"{pre}cblas_ddot{suf}")
+                    except AttributeError:
+                        continue
+                    hooks = BlasHooks(ctypes.cast(gemv, ctypes.c_void_p), ctypes.cast(dot, ctypes.c_void_p), ilp64)
+                    hooks._keep = handle
+                    _blas = hooks
+                    return _blas
+        except Exception:
+            _blas = None
+    return _blas
+
+
+def host_lib():
+    """Load libmeshvae_host.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise MeshVaeHostError(f"{HOST_LIB_PATH} is missing: build it with `make -C mesh-vae_amd/csrc host` "
+                                   "(or __graft_entry__.build())")
+        handle = ctypes.CDLL(HOST_LIB_PATH)
+        for name, (res, args) in HOST_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.mvhh_version() != HOST_ABI_VERSION:
+            raise MeshVaeHostError(f"libmeshvae_host.so speaks ABI {handle.mvhh_version()}, this binding {HOST_ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc == -2:
+        # the reference's heapq.heappop on an empty queue (mesh_operations.py:148)
+        raise IndexError(f"{what}: the edge queue ran dry before the requested vertex count was reached")
+    if rc != 0:
+        raise MeshVaeHostError(f"{what}: libmeshvae_host error {rc} (index out of range or bad sizes)")
+
+
+def _f64(a, cols):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise ValueError(f"expected an [n, {cols}] array, got {a.shape}")
+    return a
+
+
+def _i64(a, cols):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise ValueError(f"expected an [n, {cols}] index array, got {a.shape}")
+    return a
 
 
 # --------------------------------------------------------------------------- mesh holder / OBJ
@@ -75,60 +181,41 @@ def get_vert_connectivity(mesh_v, mesh_f):
 
 
 def get_vertices_per_edge(mesh_v, mesh_f):
-    """[E,2] vertex pairs, each undirected edge once with the smaller index first."""
-    coo = sp.coo_matrix(get_vert_connectivity(mesh_v, mesh_f))
-    pairs = np.hstack((coo.row.reshape(-1, 1), coo.col.reshape(-1, 1)))
-    return pairs[pairs[:, 0] < pairs[:, 1]]
+    """[E,2] vertex pairs, each undirected edge once with the smaller index first, in the decimator's queue order
+    (column-major COO order of the pair matrix, :33-43)."""
+    f = _i64(mesh_f, 3)
+    out = np.empty((3 * len(f), 2), dtype=np.int64)
+    n = ctypes.c_int64(0)
+    _check(host_lib().mvhh_unique_edges(f, len(f), len(mesh_v), out, ctypes.byref(n)), "get_vertices_per_edge")
+    return out[:n.value].copy()
 
 
 # --------------------------------------------------------------------------- quadrics
-def vertex_quadrics(mesh):
-    """[N,4,4]: sum over the vertex's faces of p p^T, p = the face's plane (a,b,c,d) with |(a,b,c)| = 1."""
+def face_planes(mesh):
+    """[F,4] plane (a,b,c,d) of every face with |(a,b,c)| = 1: the null vector of the face's [v | 1] rows by SVD
+    and its normalisation, face by face with the SAME numpy entry points the reference uses (:58-61; the stacked
+    svd and the axis form of norm agree with them only to the last bits, and those decide collapse ties)."""
     v, f = np.asarray(mesh.v, dtype=np.float64), np.asarray(mesh.f)
     corners = np.concatenate((v[f], np.ones((len(f), 3, 1))), axis=2)       # [F,3,4]: rows (x, y, z, 1)
-    # Null vector of each 3x4 system and its normalisation, face by face with the SAME numpy entry points the
-    # reference uses (one np.linalg.svd and one vector np.linalg.norm, a BLAS dot, per face): the stacked
-    # svd and the axis form of norm agree with them only to the last bits, and on (nearly) coplanar
-    # neighbourhoods -- a subdivided template -- the collapse order is decided by exactly those bits.
     planes = np.empty((len(f), 4))
+    svd, norm = np.linalg.svd, np.linalg.norm
     for i, m in enumerate(corners):
-        p = np.linalg.svd(m)[2][-1].reshape(-1, 1)
-        planes[i] = (p / np.linalg.norm(p[0:3])).ravel()
-    outer = planes[:, :, None] * planes[:, None, :]
-    q = np.zeros((len(v), 4, 4))
-    for face, pp in zip(f, outer):          # face-major accumulation: the order fixes the last bits of the sums,
-        for vert in face:                   # and the collapse order is decided by comparing them
-            q[vert] += pp
-    return q
+        p = svd(m)[2][-1].reshape(-1, 1)
+        planes[i] = (p / norm(p[0:3])).ravel()
+    return planes
 
 
-class _Edge:
-    """Heap record: ordered like the tuple (cost, (r, c)); r / c are rewritten in place on collapses."""
-    __slots__ = ("cost", "r", "c")
-
-    def __init__(self, cost, r, c):
-        self.cost, self.r, self.c = cost, r, c
-
-    def __lt__(self, other):
-        if self.cost != other.cost:
-            return self.cost < other.cost
-        if self.r != other.r:
-            return self.r < other.r
-        return self.c < other.c
-
-
-def _pair_costs(q, r, c, v):
-    """Quadric error of keeping r's position / keeping c's position for the merged pair, and the summed quadric."""
-    qs = q[r] + q[c]
-    pr = np.append(v[r], 1.0).reshape(-1, 1)
-    pc = np.append(v[c], 1.0).reshape(-1, 1)
-    keep_r = float(pr.T.dot(qs).dot(pr)[0, 0])      # error if c is destroyed
-    keep_c = float(pc.T.dot(qs).dot(pc)[0, 0])      # error if r is destroyed
-    return keep_r, keep_c, qs
+def vertex_quadrics(mesh):
+    """[N,4,4]: sum over the vertex's faces of p p^T, p = the face's plane (:45-70)."""
+    f = _i64(mesh.f, 3)
+    n = len(mesh.v)
+    q = np.empty((n, 16))
+    _check(host_lib().mvhh_vertex_quadrics(face_planes(mesh), f, len(f), n, q), "vertex_quadrics")
+    return q.reshape(n, 4, 4)
 
 
 def _selection_transform(faces, n_original):
-    """Renumber the surviving vertices 0..m-1 (ascending old index) and the one-hot [m, n_original] matrix."""
+    """Renumber the surviving vertices 0..m-1 (ascending old index) and the one-hot [m, n_original] matrix (:72-85)."""
     left = np.unique(faces.ravel())
     remap = np.arange(0, np.max(faces.ravel()) + 1)
     remap[left] = np.arange(len(left))
@@ -141,163 +228,32 @@ def qslim_decimator_transformer(mesh, factor=None, n_verts_desired=None):
     """-> (new_faces [F',3], D sparse [n', n]) keeping ceil(n * factor) (or n_verts_desired) vertices."""
     if factor is None and n_verts_desired is None:
         raise Exception('Need either factor or n_verts_desired.')
-    v = np.asarray(mesh.v, dtype=np.float64)
+    v, f = _f64(mesh.v, 3), _i64(mesh.f, 3)
     n = len(v)
     if n_verts_desired is None:
         n_verts_desired = math.ceil(n * factor)
-    q = vertex_quadrics(mesh)
-
-    # undirected edges in the reference's queue order: COO entries of the symmetrised pair matrix with r <= c
-    pairs = get_vertices_per_edge(v, mesh.f)
-    adj = sp.csc_matrix((pairs[:, 0] * 0 + 1, (pairs[:, 0], pairs[:, 1])), shape=(n, n))
-    adj = (adj + adj.T).tocoo()
-    heap, touching = [], [[] for _ in range(n)]
-    for r, c in zip(adj.row, adj.col):
-        if r > c:
-            continue
-        keep_r, keep_c, _ = _pair_costs(q, r, c, v)
-        e = _Edge(keep_c if keep_c < keep_r else keep_r, int(r), int(c))
-        heapq.heappush(heap, e)
-        touching[r].append(e)
-        touching[c].append(e)
-
-    faces = np.asarray(mesh.f).copy()
-    live = np.ones(len(faces), dtype=bool)
-    uses = np.bincount(faces.ravel(), minlength=n)
-    n_left = int(np.count_nonzero(uses))
-    while n_left > n_verts_desired:
-        e = heapq.heappop(heap)
-        r, c = e.r, e.c
-        if r == c:
-            continue
-        keep_r, keep_c, qs = _pair_costs(q, r, c, v)
-        now = keep_c if keep_c < keep_r else keep_r
-        if now > e.cost:                       # stale: the endpoints' quadrics grew since it was queued
-            fresh = _Edge(now, r, c)
-            heapq.heappush(heap, fresh)
-            touching[r].append(fresh)
-            touching[c].append(fresh)
-            continue
-        gone, kept = (c, r) if keep_r < keep_c else (r, c)
-        # faces: rename the vertex, drop what became degenerate
-        hit = live & np.any(faces == gone, axis=1)
-        rows = np.nonzero(hit)[0]
-        sub = faces[rows]
-        k = int(np.count_nonzero(sub == gone))
-        sub[sub == gone] = kept
-        faces[rows] = sub
-        uses[kept] += k
-        if uses[gone] > 0:
-            n_left -= 1
-        uses[gone] = 0
-        dead = (sub[:, 0] == sub[:, 1]) | (sub[:, 1] == sub[:, 2]) | (sub[:, 2] == sub[:, 0])
-        if dead.any():
-            live[rows[dead]] = False
-            for vert in sub[dead].ravel():
-                uses[vert] -= 1
-                if uses[vert] == 0:
-                    n_left -= 1
-        # queue: every record that mentions the vanished vertex now mentions the kept one
-        for rec in touching[gone]:
-            if rec.r == gone:
-                rec.r = kept
-            if rec.c == gone:
-                rec.c = kept
-        touching[kept].extend(touching[gone])
-        touching[gone] = []
-        q[r] = qs
-        q[c] = qs
-    return _selection_transform(faces[live], n)
+    q = np.ascontiguousarray(vertex_quadrics(mesh).reshape(n, 16))
+    edges = get_vertices_per_edge(v, f)
+    kept_faces = np.empty_like(f)
+    n_faces, n_coll = ctypes.c_int64(0), ctypes.c_int64(0)
+    blas = numpy_cblas()
+    _check(host_lib().mvhh_qslim_decimate(v, n, f, len(f), q, edges, len(edges), int(n_verts_desired), kept_faces,
+                                          ctypes.byref(n_faces), ctypes.byref(n_coll),
+                                          ctypes.byref(blas) if blas is not None else None), "qslim_decimator_transformer")
+    return _selection_transform(kept_faces[:n_faces.value], n)
 
 
 # --------------------------------------------------------------------------- closest point / upsampling
-def _closest_on_triangles(p, a, ab, ac, b, c):
-    """Closest point of every triangle (a, a+ab, a+ac) to the point p, with the region code of psbody's
-    AABB query: 0 interior, 1/2/3 edge ab/bc/ca, 4/5/6 vertex a/b/c (Ericson, Real-Time Collision Detection 5.1.5)."""
-    ap, bp, cp = p - a, p - b, p - c
-    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
-    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
-    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
-    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
-    m = a.shape[0]
-    out = np.empty((m, 3))
-    code = np.full(m, -1, dtype=np.int64)
-    open_ = np.ones(m, dtype=bool)
-
-    def settle(mask, pts, region):
-        sel = mask & open_
-        out[sel] = pts[sel]
-        code[sel] = region
-        open_[sel] = False
-
-    with np.errstate(divide="ignore", invalid="ignore"):
-        settle((d1 <= 0) & (d2 <= 0), a, 4)
-        settle((d3 >= 0) & (d4 <= d3), b, 5)
-        settle((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + (d1 / (d1 - d3))[:, None] * ab, 1)
-        settle((d6 >= 0) & (d5 <= d6), c, 6)
-        settle((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + (d2 / (d2 - d6))[:, None] * ac, 3)
-        w = (d4 - d3) / ((d4 - d3) + (d5 - d6))
-        settle((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), b + w[:, None] * (c - b), 2)
-        den = 1.0 / (va + vb + vc)
-        settle(np.ones(m, dtype=bool), a + ab * (vb * den)[:, None] + ac * (vc * den)[:, None], 0)
-    return out, code
-
-
-def _nearest_exhaustive(points, a, ab, ac, b, c):
-    n = len(points)
+def nearest_on_surface(source, points, exhaustive=False):
+    """For every point: (face index, region code, closest point) on the triangle mesh `source`: region 0 interior,
+    1/2/3 edge ab/bc/ca, 4/5/6 vertex a/b/c; the first minimum over the faces wins (psbody's AABB-tree `nearest`,
+    :208-209, returns this triple).  `exhaustive` tests every triangle instead of walking the hierarchy."""
+    sv, sf = _f64(source.v, 3), _i64(source.f, 3)
+    pts = _f64(np.asarray(points, dtype=np.float64).reshape(-1, 3), 3)
+    n = len(pts)
     face, region, hit = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros((n, 3))
-    for i in range(n):
-        pts, code = _closest_on_triangles(points[i], a, ab, ac, b, c)
-        j = int(np.argmin(((pts - points[i]) ** 2).sum(-1)))
-        face[i], region[i], hit[i] = j, code[j], pts[j]
-    return face, region, hit
-
-
-def nearest_on_surface(source, points, chunk_pairs=1 << 21):
-    """For every point: (face index, region code, closest point) on the triangle mesh `source` (first minimum wins).
-
-    Same result as testing every triangle for every point (the arithmetic per (point, triangle) pair is
-    elementwise and unchanged), but only the triangles that can hold the minimum are tested: the distance
-    d0 to the nearest mesh vertex bounds the distance to the surface, and a triangle within d0 of the point
-    has its centroid within d0 + r_max (r_max = largest centroid-to-corner distance).  Candidates are
-    visited in ascending face order, so ties resolve to the lowest face index as in the exhaustive scan.
-    20k-vertex template: 108 s -> ~2 s."""
-    from scipy.spatial import cKDTree
-    sv, sf = np.asarray(source.v, dtype=np.float64), np.asarray(source.f, dtype=np.int64)
-    a, b, c = sv[sf[:, 0]], sv[sf[:, 1]], sv[sf[:, 2]]
-    ab, ac = b - a, c - a
-    points = np.asarray(points, dtype=np.float64)
-    n = len(points)
-    area2 = (np.cross(ab, ac) ** 2).sum(-1)
-    if n == 0 or len(sf) < 64 or not np.all(np.isfinite(area2)) or np.any(area2 == 0):
-        return _nearest_exhaustive(points, a, ab, ac, b, c)     # tiny or degenerate input: no pruning
-    cen = (a + b + c) / 3.0
-    r_max = float(np.sqrt(max(((a - cen) ** 2).sum(-1).max(), ((b - cen) ** 2).sum(-1).max(),
-                              ((c - cen) ** 2).sum(-1).max())))
-    d0, _ = cKDTree(sv[np.unique(sf)]).query(points)
-    radius = (d0 + r_max) * (1.0 + 1e-9) + 1e-12 * r_max
-    cand = cKDTree(cen).query_ball_point(points, radius, return_sorted=True)
-    counts = np.fromiter((len(t) for t in cand), dtype=np.int64, count=n)
-    face, region, hit = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros((n, 3))
-    lo = 0
-    while lo < n:                                         # chunks of whole points, bounded pair count
-        hi, tot = lo, 0
-        while hi < n and (hi == lo or tot + counts[hi] <= chunk_pairs):
-            tot += counts[hi]
-            hi += 1
-        pf = np.concatenate([np.asarray(cand[i], dtype=np.int64) for i in range(lo, hi)])
-        pp = np.repeat(np.arange(lo, hi), counts[lo:hi])
-        pts, code = _closest_on_triangles(points[pp], a[pf], ab[pf], ac[pf], b[pf], c[pf])
-        d = ((pts - points[pp]) ** 2).sum(-1)
-        if np.any(np.isnan(d)):
-            return _nearest_exhaustive(points, a, ab, ac, b, c)
-        starts = np.concatenate(([0], np.cumsum(counts[lo:hi])[:-1]))
-        seg_min = np.minimum.reduceat(d, starts)
-        at_min = np.flatnonzero(d == np.repeat(seg_min, counts[lo:hi]))
-        owner = pp[at_min]
-        first = at_min[np.concatenate(([True], owner[1:] != owner[:-1]))]
-        face[lo:hi], region[lo:hi], hit[lo:hi] = pf[first], code[first], pts[first]
-        lo = hi
+    _check(host_lib().mvhh_closest_points(sv, len(sv), sf, len(sf), pts, n, 1 if exhaustive else 0, face, region, hit),
+           "nearest_on_surface")
     return face, region, hit
 
 
@@ -309,6 +265,7 @@ def setup_deformation_transfer(source, target, use_normals=False):
     n = tv.shape[0]
     rows, cols, coef = np.zeros(3 * n), np.zeros(3 * n), np.zeros(3 * n)
     face, region, hit = nearest_on_surface(source, tv)
+    lstsq = np.linalg.lstsq
     for i in range(n):
         tri = sf[face[i]]
         rows[3 * i:3 * i + 3] = i
@@ -316,10 +273,10 @@ def setup_deformation_transfer(source, target, use_normals=False):
         part = int(region[i])
         if part == 0:                                     # inside the triangle: weights of its three vertices
             basis = np.vstack((sv[tri])).T
-            coef[3 * i:3 * i + 3] = np.linalg.lstsq(basis, hit[i], rcond=None)[0]
+            coef[3 * i:3 * i + 3] = lstsq(basis, hit[i], rcond=None)[0]
         elif part <= 3:                                   # on an edge: the target itself over the edge's two vertices
             basis = np.vstack((sv[tri[part - 1]], sv[tri[part % 3]])).T
-            w = np.linalg.lstsq(basis, tv[i], rcond=None)[0]
+            w = lstsq(basis, tv[i], rcond=None)[0]
             coef[3 * i + part - 1] = w[0]
             coef[3 * i + part % 3] = w[1]
         else:                                             # at a vertex

@@ -28,6 +28,26 @@ def test_library_exports_every_header_symbol():
     assert lib.mvh_version() == meshvae_hip.ABI_VERSION == 300
 
 
+def test_host_library_exports_every_header_symbol():
+    """libmeshvae_host.so (the C++ half of the hierarchy generator): header <-> exports <-> ctypes signatures."""
+    import ctypes
+    import mesh_operations as mo
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "meshvae_host.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mvhh_[a-z0-9_]+)\s*\(", text)))
+    assert len(syms) == 5
+    lib = mo.host_lib()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/meshvae_host.h but not exported"
+    assert sorted(mo.HOST_SIGNATURES) == syms
+    assert lib.mvhh_version() == mo.HOST_ABI_VERSION == 100
+    # error convention: negative codes, surfaced as Python exceptions by the binding
+    f = np.array([[0, 1, 7]], dtype=np.int64)
+    out, n = np.empty((3, 2), dtype=np.int64), ctypes.c_int64(0)
+    assert lib.mvhh_unique_edges(f, 1, 3, out, ctypes.byref(n)) == -1        # vertex 7 of 3
+    with pytest.raises(mo.MeshVaeHostError, match="out of range"):
+        mo.get_vertices_per_edge(np.zeros((3, 3)), f)
+
+
 def test_argument_validation_without_gpu():
     """Host-side checks fire before any kernel launch."""
     import ctypes

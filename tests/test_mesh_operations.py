@@ -1,7 +1,8 @@
-"""CPU: the build's hierarchy generator (mesh-vae_amd/mesh_operations.py) against the
-A / D / U hierarchies captured from the reference's own generator (tests/golden/topology_*.npz):
-adjacency and decimation exactly (entry order included), upsampling weights to 1e-12 (its closest-point
-search is the stand-in's in both cases, psbody being unpinned -- see DESIGN.md section 2)."""
+"""CPU: the build's hierarchy generator (mesh-vae_amd/mesh_operations.py over the C++ library
+libmeshvae_host.so) against the A / D / U hierarchies captured from the reference's own
+generator (tests/golden/topology_*.npz): adjacency and decimation exactly (entry order included), upsampling
+weights to 1e-6 (its closest-point search is the stand-in's in both cases, psbody being unpinned -- see
+DESIGN.md section 2), and piece by piece against the numpy restatement oracle/hierarchy_oracle.py."""
 import os
 import time
 
@@ -10,6 +11,7 @@ import pytest
 
 import mesh_operations as mo
 from conftest import load_golden
+from oracle import hierarchy_oracle as ho
 from meshgen import subdivide, torus_mesh
 
 # The reference's template OBJ is a third-party asset and is not committed: the real-template cases run
@@ -71,10 +73,13 @@ def test_obj_reader_and_edges(tmp_path):
 @needs_ref_template
 def test_subdivided_20k_hierarchy_matches_reference(topo20k_npz):
     """BASELINE configs[3]'s template: coplanar sub-faces give exactly tied / zero collapse costs, so this is
-    the case where the heap's tie-breaking and the last bits of the quadrics decide the result (~2 min)."""
+    the case where the heap's tie-breaking and the last bits of the quadrics decide the result: the decimator is given numpy's own CBLAS entry points (mesh_operations.numpy_cblas) so that the
+    costs of tied pairs carry the reference's last bits."""
     t = mo.Mesh(filename=REF_TEMPLATE)
     v, f = subdivide(t.v, t.f)
+    t0 = time.time()
     M, A, D, U = mo.generate_transform_matrices(mo.Mesh(v=v, f=f), [4, 4, 4, 4, 4])
+    print(f"20k hierarchy in {time.time() - t0:.1f} s")
     _check(M, A, D, U, topo20k_npz, 6)
 
 
@@ -106,21 +111,75 @@ def test_get_model_builds_the_hierarchy_from_the_template(tmp_path, topotiny_npz
     assert (tmp_path / "initial_weight.pt").exists()
 
 
-def test_pruned_closest_point_equals_exhaustive_scan():
-    """nearest_on_surface's candidate pruning returns exactly what the all-triangles scan returns: faces, region
-    codes and hit points, for points on, near and far from the surface (ties resolve to the lowest face)."""
-    mesh = mo.Mesh(*torus_mesh(51, 98))
-    g = np.random.default_rng(0)
+def _closest_point_cases(mesh, g, n_each=40):
     v = mesh.v
-    pick = g.choice(len(v), 120, replace=False)
+    pick = g.choice(len(v), 3 * n_each, replace=False)
     span = np.ptp(v, axis=0).max()
-    pts = np.concatenate([v[pick[:40]],                                            # exactly on vertices (ties)
-                          v[pick[40:80]] + g.standard_normal((40, 3)) * 0.01 * span,  # near the surface
-                          v[pick[80:]] + g.standard_normal((40, 3)) * 2.0 * span])    # far away
+    mid = 0.5 * (v[mesh.f[:n_each, 0]] + v[mesh.f[:n_each, 1]])
+    return np.concatenate([v[pick[:n_each]],                                                     # exactly on vertices (ties)
+                           mid,                                                                    # exactly on edges (two faces tie)
+                           v[pick[n_each:2 * n_each]] + g.standard_normal((n_each, 3)) * 0.01 * span,  # near the surface
+                           v[pick[2 * n_each:]] + g.standard_normal((n_each, 3)) * 2.0 * span])    # far away
+
+
+def test_bvh_closest_point_equals_exhaustive_scan_and_numpy_oracle():
+    """mvhh_closest_points: the hierarchy walk returns exactly what its own all-triangles scan and the numpy oracle's
+    scan return -- faces, region codes and hit points bit for bit, for points on, near and far from the surface
+    (ties resolve to the lowest face)."""
+    mesh = mo.Mesh(*torus_mesh(51, 98))
+    pts = _closest_point_cases(mesh, np.random.default_rng(0))
     sf = np.asarray(mesh.f, dtype=np.int64)
-    a, b, c = v[sf[:, 0]], v[sf[:, 1]], v[sf[:, 2]]
-    f0, r0, h0 = mo._nearest_exhaustive(pts, a, b - a, c - a, b, c)
+    a, b, c = mesh.v[sf[:, 0]], mesh.v[sf[:, 1]], mesh.v[sf[:, 2]]
+    f0, r0, h0 = ho._nearest_exhaustive(pts, a, b - a, c - a, b, c)
     f1, r1, h1 = mo.nearest_on_surface(mesh, pts)
-    f2, r2, h2 = mo.nearest_on_surface(mesh, pts, chunk_pairs=50)                  # many small chunks
+    f2, r2, h2 = mo.nearest_on_surface(mesh, pts, exhaustive=True)
+    assert len(set(r0.tolist())) >= 4            # interior, edge and vertex regions all occur
     for f, r, h in ((f1, r1, h1), (f2, r2, h2)):
         assert np.array_equal(f, f0) and np.array_equal(r, r0) and np.array_equal(h, h0)
+
+
+def test_closest_point_degenerate_triangles_follow_the_full_scan():
+    """A zero-area triangle makes distances NaN for some points; the library then takes the all-triangles scan with
+    numpy's argmin rule (the first NaN wins) -- same answers as the oracle's exhaustive search."""
+    v, f = torus_mesh(9, 12)
+    f = np.concatenate([f[:5], [[3, 3, 3]], f[5:]])            # a point triangle in the middle of the list
+    mesh = mo.Mesh(v, f)
+    pts = _closest_point_cases(mo.Mesh(v, f[:5]), np.random.default_rng(1), n_each=5)
+    sf = np.asarray(f, dtype=np.int64)
+    a, b, c = v[sf[:, 0]], v[sf[:, 1]], v[sf[:, 2]]
+    with np.errstate(all="ignore"):
+        f0, r0, h0 = ho._nearest_exhaustive(pts, a, b - a, c - a, b, c)
+    f1, r1, h1 = mo.nearest_on_surface(mesh, pts)
+    assert np.array_equal(f1, f0) and np.array_equal(r1, r0) and np.array_equal(h1, h0, equal_nan=True)
+
+
+def test_decimator_pieces_against_the_numpy_oracle():
+    """Edge queue order, quadrics, surviving faces (order and rotation included) and D of one decimation, C++ against
+    the numpy restatement, on the torus; with the caller's CBLAS and with the library's built-in cost arithmetic."""
+    v, f = torus_mesh(21, 30)
+    mesh, omesh = mo.Mesh(v, f), ho.Mesh(v, f)
+    assert np.array_equal(mo.get_vertices_per_edge(v, f), ho.get_vertices_per_edge(v, f))
+    assert np.array_equal(mo.vertex_quadrics(mesh), ho.vertex_quadrics(omesh))
+    nf0, d0 = ho.qslim_decimator_transformer(omesh, factor=0.25)
+    nf1, d1 = mo.qslim_decimator_transformer(mesh, factor=0.25)
+    assert mo.numpy_cblas() is not None, "numpy's CBLAS entry points were not found (threadpoolctl)"
+    assert np.array_equal(nf1, nf0) and np.array_equal(d1.tocoo().col, d0.tocoo().col)
+    nf2, d2 = mo.qslim_decimator_transformer(mesh, n_verts_desired=d0.shape[0])
+    assert np.array_equal(nf2, nf0)
+    old, mo._blas = mo._blas, None                              # the built-in evaluation order (no BLAS hooks)
+    try:
+        nf3, d3 = mo.qslim_decimator_transformer(mesh, factor=0.25)
+    finally:
+        mo._blas = old
+    assert np.array_equal(d3.tocoo().col, d0.tocoo().col) and np.array_equal(nf3, nf0)
+
+
+def test_decimator_runs_dry_like_the_reference():
+    """A vertex count the mesh cannot reach (every face gone and still above the target) ends in the reference's
+    IndexError (heappop on an empty queue, mesh_operations.py:148), not in a hang or a wrong answer."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
+    f = np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]])
+    with pytest.raises(IndexError):
+        mo.qslim_decimator_transformer(mo.Mesh(v, f), n_verts_desired=-1)
+    with pytest.raises(IndexError):
+        ho.qslim_decimator_transformer(ho.Mesh(v, f), n_verts_desired=-1)
