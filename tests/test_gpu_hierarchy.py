@@ -70,7 +70,7 @@ def test_template_to_train_step_on_the_gpu_box(tmp_path, capsys):
     lo, co, ro, (ko, reco, zo), yo, _, _ = ora.forward(x, x.clone(), y, "train")
     lo.backward()
     assert (recon.detach().cpu() - ro.detach()).abs().max().item() < 1e-4
-    assert abs(float(loss) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
+    assert abs(loss.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item()))
     for k, g in ora.grads().items():
         got = dict(net.named_parameters())[k].grad.cpu()
         rel = (got - g).norm().item() / max(g.norm().item(), 1e-12)
