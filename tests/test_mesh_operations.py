@@ -183,3 +183,27 @@ def test_decimator_runs_dry_like_the_reference():
         mo.qslim_decimator_transformer(mo.Mesh(v, f), n_verts_desired=-1)
     with pytest.raises(IndexError):
         ho.qslim_decimator_transformer(ho.Mesh(v, f), n_verts_desired=-1)
+
+
+def test_integration_md_host_stub_runs_as_written():
+    """The ctypes stub INTEGRATION.md shows for libmeshvae_host.so, executed as written (only the library path is made
+    absolute): its surviving faces are the product binding's and the oracle's."""
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = [c for c in re.findall(r"```python\n(.*?)```", text, re.S) if "libmeshvae_host.so" in c][0]
+    code = code.replace('"/path/to/repo/mesh-vae_amd/meshvae_hip/libmeshvae_host.so"', repr(mo.HOST_LIB_PATH))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    v, f = torus_mesh(21, 30)
+    mesh = mo.Mesh(v, f)
+    old, mo._blas = mo._blas, None                    # (the stub passes no BLAS hooks)
+    try:
+        nf, d = mo.qslim_decimator_transformer(mesh, n_verts_desired=160)
+    finally:
+        mo._blas = old
+    faces = ns["qslim_faces"](np.ascontiguousarray(v), np.ascontiguousarray(f, dtype=np.int64), mo.face_planes(mesh), 160)
+    nf2, d2 = mo._selection_transform(faces, len(v))
+    assert np.array_equal(nf2, nf) and np.array_equal(d2.tocoo().col, d.tocoo().col)
+    nf0, _ = ho.qslim_decimator_transformer(ho.Mesh(v, f), n_verts_desired=160)
+    assert np.array_equal(nf, nf0)
