@@ -207,3 +207,37 @@ def test_integration_md_host_stub_runs_as_written():
     assert np.array_equal(nf2, nf) and np.array_equal(d2.tocoo().col, d.tocoo().col)
     nf0, _ = ho.qslim_decimator_transformer(ho.Mesh(v, f), n_verts_desired=160)
     assert np.array_equal(nf, nf0)
+
+
+def _jittered_torus(nu, nv, seed, amp):
+    """A torus grid with every vertex moved by a seeded random offset (generic geometry: no exact cost ties), faces
+    unchanged."""
+    v, f = torus_mesh(nu, nv)
+    g = np.random.default_rng(seed)
+    span = np.ptp(v, axis=0).max()
+    return v + g.standard_normal(v.shape) * amp * span / max(nu, nv), f
+
+
+@pytest.mark.parametrize("nu,nv,seed,amp,factor", [(9, 14, 1, 0.2, 0.5), (12, 17, 2, 0.05, 0.25), (16, 23, 3, 0.3, 0.125),
+                                                   (7, 31, 4, 0.1, 0.34), (20, 20, 5, 0.0, 0.25)])
+def test_random_meshes_cpp_hierarchy_equals_numpy_oracle(nu, nv, seed, amp, factor):
+    """Whole levels on seeded random geometry, C++ against the numpy restatement: the surviving faces (order and rotation),
+    D, the closest-point triples of the fine vertices on the coarse surface, and U entry for entry (amp = 0: the regular
+    torus, where whole rings of edges have EQUAL costs up to rounding -- the heap's tie-breaking decides)."""
+    v, f = _jittered_torus(nu, nv, seed, amp)
+    fine, ofine = mo.Mesh(v, f), ho.Mesh(v, f)
+    nf0, d0 = ho.qslim_decimator_transformer(ofine, factor=factor)
+    nf1, d1 = mo.qslim_decimator_transformer(fine, factor=factor)
+    assert np.array_equal(nf1, nf0)
+    assert np.array_equal(d1.tocoo().col, d0.tocoo().col) and d1.shape == d0.shape
+    coarse = mo.Mesh(v=d1.dot(v), f=nf1)
+    f1, r1, h1 = mo.nearest_on_surface(coarse, v)
+    f0, r0, h0 = ho.nearest_on_surface(ho.Mesh(v=coarse.v, f=coarse.f), v)
+    assert np.array_equal(f1, f0) and np.array_equal(r1, r0) and np.array_equal(h1, h0)
+    u1 = mo.setup_deformation_transfer(coarse, fine).tocoo()
+    u0 = ho.setup_deformation_transfer(ho.Mesh(v=coarse.v, f=coarse.f), ofine).tocoo()
+    assert np.array_equal(u1.row, u0.row) and np.array_equal(u1.col, u0.col) and np.array_equal(u1.data, u0.data)
+    # the defining property of U D on the kept vertices: a kept fine vertex is reproduced from itself
+    kept = d1.tocoo().col
+    back = u1.tocsr()[kept].dot(coarse.v)
+    np.testing.assert_allclose(back, v[kept], rtol=0, atol=1e-9 * np.ptp(v))
