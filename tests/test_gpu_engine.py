@@ -41,6 +41,52 @@ def test_fused_adam_matches_torch_adam():
     assert int(opt.step_count) == 5
 
 
+def test_fused_adam_vector_and_scalar_paths_agree_bitwise():
+    """k_adam updates four parameters per thread through 16-byte accesses when all four buffers are 16-byte aligned and
+    the group is not cut by the no-gradient range; element-wise otherwise.  Both forms are the same arithmetic: buffers
+    shifted by one float (scalar path everywhere) give bitwise the aligned run's result, for a size that is not a
+    multiple of four, a skip range that starts and ends inside groups, the host-counted and the device-counted form."""
+    from meshvae_hip import check, lib
+    dev = torch.device("cuda:0")
+    n, lo, hi = 4099, 1022, 1031
+    g = torch.Generator().manual_seed(5)
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    res = {}
+    for shift in (0, 1):
+        for counted in (True, False):
+            bufs = [torch.zeros(n + 4, device=dev) for _ in range(4)]
+            p, gr, m, v = (b[shift:shift + n] for b in bufs)
+            p.copy_(p0)
+            gr.copy_(g0)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            for step in (1, 2, 3):
+                args = (p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 5e-4, 0.5, cnt.data_ptr())
+                if counted:
+                    check(lib().mvh_adam_step_counted(st, *args, step, lo, hi))
+                else:
+                    check(lib().mvh_adam_step(st, *args, lo, hi))
+            torch.cuda.synchronize()
+            assert int(cnt) == 3
+            assert all(float(b[:shift].abs().sum()) == 0 and float(b[shift + n:].abs().sum()) == 0 for b in bufs[2:])   # no stray writes
+            res[(shift, counted)] = (p.cpu().clone(), m.cpu().clone(), v.cpu().clone())
+    ref = res[(0, True)]
+    assert torch.equal(ref[0][lo:hi], p0[lo:hi]) and float(ref[1][lo:hi].abs().sum()) == 0     # the skipped range is untouched
+    assert not torch.equal(ref[0][:lo], p0[:lo])
+    for key, got in res.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), key
+    # ... and against torch.optim.Adam on the same numbers (grad_scale folded into the gradient)
+    tp = torch.nn.Parameter(p0.clone().to(dev))
+    topt = torch.optim.Adam([tp], lr=1e-3, weight_decay=5e-4)
+    for _ in range(3):
+        tp.grad = (g0 * 0.5).to(dev)
+        topt.step()
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[lo:hi] = False
+    torch.testing.assert_close(ref[0][keep], tp.detach().cpu()[keep], rtol=1e-5, atol=1e-7)
+
+
 def test_trainstep_graph_equals_eager_and_learns():
     from meshvae_hip.engine import TrainStep
     dev = torch.device("cuda:0")
