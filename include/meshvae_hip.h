@@ -178,6 +178,32 @@ int mvh_cheb_conv_bwd_bf16(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_
                            int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
                            void* ws, size_t ws_bytes);
 
+/* ---- strided inputs across the boundary (last row).  The reference's modules hand NON-contiguous views
+ * to their arithmetic -- ChebConv_batch.forward transposes to [N, B, C] (nn/conv.py:560, 565, 570), SurfacePool.forward
+ * does the same (nn/pool.py:18-20) -- so a caller may hold its activations vertex-major.  These entries take x as a
+ * [B, N, C] VIEW given by element strides (x_mesh_stride, x_row_stride, 1): e.g. (C, B*C) for the transpose of an
+ * [N, B, C]-physical tensor, (2*N*C, C) for every other mesh of a batch.  No copy is made: the LDS-resident kernels
+ * read the rows in place.  Requirements: both strides multiples of Cin (pool: any positive row stride), rows 16-byte
+ * aligned when Cin % 4 == 0, x_mesh_stride > 0.  Outputs and gradients are contiguous; everything else is as in
+ * mvh_cheb_conv_fwd_signs / _bwd_signs (relu_signs != NULL, act = RELU) or mvh_cheb_conv_fwd / _bwd (relu_signs ==
+ * NULL; the backward's ReLU mask is then `out`).  Layers the LDS-resident kernels do not take (N + 1 > 5120, the
+ * mostly-isolated final-layer form, Cin not in {3, 8, 16, 32}, ...) return MVH_ERR_UNSUPPORTED and nothing is written:
+ * the caller copies x and uses the contiguous entry.  ws: mvh_cheb_conv_strided_ws_bytes for both directions. */
+size_t mvh_cheb_conv_strided_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K);
+int mvh_cheb_conv_fwd_strided(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, int64_t x_mesh_stride,
+                              int64_t x_row_stride, const float* W, const float* bias, float* out, uint8_t* relu_signs,
+                              int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                              void* ws, size_t ws_bytes);
+int mvh_cheb_conv_bwd_strided(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
+                              int64_t x_mesh_stride, int64_t x_row_stride, const float* W, const float* out,
+                              const uint8_t* relu_signs, const float* dout, float* dx, float* dW, float* db,
+                              int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act,
+                              void* ws, size_t ws_bytes);
+/* SurfacePool.forward (nn/pool.py:17-20) on such a view: y[B,n_rows,C] (contiguous) = P x, bit for bit
+ * mvh_pool_fwd on the contiguous copy (any level; its backward reads only the contiguous dy: mvh_pool_bwd). */
+int mvh_pool_fwd_strided(mvh_stream_t stream, const mvh_csr_t* pool, const float* x, int64_t x_mesh_stride,
+                         int64_t x_row_stride, float* y, int32_t B, int32_t C);
+
 /* ---- rows E/D (dense parts): nn.Linear + F.relu + nn.Dropout (cheb_VAE.py:270-272,277-280).
  * y[B,out] = drop( act( x[B,in] W[out,in]^T + bias ) ); drop keeps element i when
  * drop_u[i] >= p and scales by 1/(1-p); drop_u == NULL or p == 0 disables it. */

@@ -164,6 +164,39 @@ extern "C" int mvh_pool_fwd(mvh_stream_t stream, const mvh_csr_t* pool, const fl
   return launch_spmm((hipStream_t)stream, pool, x, y, nullptr, nullptr, 1.f, 0.f, B, C, true);
 }
 
+// SurfacePool.forward on a strided [B, n_cols, C] view (element strides x_mesh_stride, x_row_stride, 1; nn/pool.py:18
+// hands the transposed view of its input to propagate): one thread per (mesh, output row, channel), products and adds
+// rounded separately in edge order -- bit for bit mvh_pool_fwd on the contiguous copy.  y is contiguous.
+__global__ void __launch_bounds__(256)
+k_pool_strided(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val, int n_rows,
+               const float* __restrict__ x, long long ms, long long rs, float* __restrict__ y, int C, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long br = i / C;
+  const int r = (int)(br % n_rows);
+  const long long b = br / n_rows;
+  const float* xb = x + b * ms + c;
+  float acc = 0.f;
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) acc = __fadd_rn(acc, __fmul_rn(val[e], xb[(long long)col[e] * rs]));
+  y[i] = acc;
+}
+
+extern "C" int mvh_pool_fwd_strided(mvh_stream_t stream, const mvh_csr_t* pool, const float* x, int64_t x_mesh_stride,
+                                    int64_t x_row_stride, float* y, int32_t B, int32_t C) {
+  if (int rc = check_csr(pool, "pool_fwd_strided")) return rc;
+  MVH_REQUIRE(x && y, "pool_fwd_strided: null tensor");
+  MVH_REQUIRE(B >= 0 && C > 0 && x_mesh_stride >= 0 && x_row_stride > 0, "pool_fwd_strided: bad sizes B=%d C=%d", B, C);
+  const long long total = (long long)B * pool->n_rows * C;
+  if (total == 0) return MVH_OK;
+  const long long nblk = (total + 255) / 256;
+  MVH_REQUIRE(nblk < (1ll << 31), "pool_fwd_strided: grid too large");
+  hipLaunchKernelGGL(k_pool_strided, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pool->rowptr, pool->col,
+                     pool->val, pool->n_rows, x, (long long)x_mesh_stride, (long long)x_row_stride, y, C, total);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
 extern "C" int mvh_pool_bwd(mvh_stream_t stream, const mvh_csr_t* pool_t, const float* dy, float* dx,
                             int32_t B, int32_t C) {
   if (int rc = check_csr(pool_t, "pool_bwd")) return rc;

@@ -1020,6 +1020,11 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   if ((long long)B * N == 0) return MVH_OK;
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * N, plane = rows * Cin;
+  if (io.x_map) {  // strided x: the LDS-resident kernel reads it through its row map, nothing else can
+    MVH_REQUIRE(!tx_saved && !bf && io.x_bs > 0, "cheb_conv_fwd: a strided x comes without a saved stack, as fp32");
+    if (split_eligible(lap, N, Cin, Cout, K))
+      return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: strided x on a mostly-isolated Laplacian (per-vertex map path)");
+  }
   if (!tx_saved && ws && ws_bytes >= kLdsWpackBytes + kSplitScratchBytes && split_eligible(lap, N, Cin, Cout, K)) {
     const float* weff = weff_pre;
     if (!weff) {
@@ -1051,6 +1056,7 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
     LdsConvOpts fo;
     fo.prepacked = prepacked;
     fo.in_bf16 = io.x; fo.out_bf16 = io.out; fo.pooled_bf16 = io.pooled; fo.prepacked_h = io.wh;
+    if (io.x_map) { fo.in_map = io.x_map; fo.in_bs = io.x_bs; }
     if (pool && pool->sel_inv && pooled) { fo.pool_inv = pool->sel_inv; fo.pooled = pooled; fo.pooled_bs = pool->n_rows; }
     fo.bits_out = bits_out;
     fo.out_dead = io.out_dead && fo.pool_inv != nullptr && bits_out != nullptr;
@@ -1072,6 +1078,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   }
   if (bf)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: bf16 storage exists on the LDS-resident kernels only (N=%d %d->%d K=%d)",
+                N, Cin, Cout, K);
+  if (io.x_map)
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: strided x is read by the LDS-resident kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);
   float* tx = tx_saved;
   if (!tx && K > 1) {
@@ -1230,6 +1239,16 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
   }
   bool dw_done = (dW == nullptr);  // dW == NULL: dX-only call (the step engine runs dW on a side stream)
   bool dx_done = (dx == nullptr);
+  if (io.x_map && dW) {  // strided x: only the LDS-resident dW kernel reads it (through its row map)
+    MVH_REQUIRE(!tx_saved && !bf && io.x_bs > 0 && !dout_pool, "cheb_conv_bwd: a strided x comes without a saved stack, as fp32");
+    bool ok = false;
+    if (!split_eligible(lap, N, Cin, Cout, K) && N + 1 <= 5120)
+      if (int rc = try_cheb_dw_lds(stream, lap, x, dout, nullptr, dW, db, B, N, Cin, Cout, K, partial,
+                                   (size_t)((char*)ws + ws_bytes - (char*)partial), &ok, 0, nullptr, 0, true)) return rc;
+    if (!ok)
+      return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: strided x is read by the LDS-resident dW kernel only (N=%d %d->%d K=%d)",
+                  N, Cin, Cout, K);
+  }
   // 16 -> 16 on a level of 5120 .. 20480 vertices with BOTH gradients asked for: one T_k(dpre) stack, one pass over it
   // (k_big_bwd16); the forward's stack (tx_saved) is not read
   if (dW && dx && K > 1 && K <= 12 && Cin == 16 && Cout == 16 && cheb_big_eligible(lap_t, B, N, Cout, K) &&
@@ -1414,4 +1433,68 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     return rc;
   if (dx_pool_t && dx_pooled) return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
   return MVH_OK;
+}
+
+
+// ------------------------------------------------------------------ strided x at the module boundary
+// x is a [B, N, Cin] VIEW with element strides (x_mesh_stride, x_row_stride, 1) -- e.g. the transpose of an
+// [N, B, Cin]-physical tensor, as the reference's own modules hand around (nn/conv.py:560, nn/pool.py:18).  Both strides
+// must be multiples of Cin (so that a row is `Cin` consecutive elements at a row index of the flattened buffer) and the
+// rows 16-byte aligned.  The LDS-resident kernels read the rows in place through their row map (built here, in the
+// tail of `ws`: N int32); shapes those kernels do not cover return MVH_ERR_UNSUPPORTED and the caller copies.
+__global__ void __launch_bounds__(256) k_row_map(int32_t* __restrict__ map, int n, int step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) map[i] = i * step;
+}
+
+static size_t strided_map_bytes(int N) { return align_up((size_t)N * sizeof(int32_t), 256); }
+
+extern "C" size_t mvh_cheb_conv_strided_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {
+  const size_t f = mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), b = mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K);
+  return (f > b ? f : b) + 256 + strided_map_bytes(N);
+}
+
+static int strided_setup(hipStream_t st, const float* x, int64_t ms, int64_t rs, int N, int Cin, void* ws, size_t ws_bytes,
+                         ConvIO& io, size_t* inner_bytes) {
+  MVH_REQUIRE(x && Cin > 0 && N > 0, "cheb_conv_strided: null tensor or bad sizes");
+  MVH_REQUIRE(ms >= 0 && rs > 0 && ms % Cin == 0 && rs % Cin == 0, "cheb_conv_strided: strides (%lld, %lld) must be multiples of Cin = %d",
+              (long long)ms, (long long)rs, Cin);
+  MVH_REQUIRE(((uintptr_t)x % 16) == 0 && (Cin % 4 != 0 || ((ms | rs) % 4) == 0), "cheb_conv_strided: rows must be 16-byte aligned");
+  MVH_REQUIRE(rs / Cin * (long long)(N - 1) < (1ll << 31) && ms / Cin < (1ll << 31), "cheb_conv_strided: strides too large");
+  const size_t mb = strided_map_bytes(N);
+  MVH_REQUIRE(ws && ws_bytes > mb + 256, "cheb_conv_strided: workspace too small (mvh_cheb_conv_strided_ws_bytes)");
+  *inner_bytes = (ws_bytes - mb) / 256 * 256;
+  int32_t* map = reinterpret_cast<int32_t*>((char*)ws + *inner_bytes);
+  hipLaunchKernelGGL(k_row_map, dim3(cdiv(N, 256)), dim3(256), 0, st, map, N, (int)(rs / Cin));
+  MVH_LAUNCH_CHECK();
+  io.x_map = map;
+  io.x_bs = (int)(ms / Cin);
+  MVH_REQUIRE(io.x_bs > 0, "cheb_conv_strided: mesh stride 0 (a broadcast batch) is not supported");
+  return MVH_OK;
+}
+
+extern "C" int mvh_cheb_conv_fwd_strided(mvh_stream_t stream, const mvh_csr_t* lap, const float* x, int64_t x_mesh_stride,
+                                         int64_t x_row_stride, const float* W, const float* bias, float* out,
+                                         uint8_t* relu_signs, int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K,
+                                         int32_t act, void* ws, size_t ws_bytes) {
+  MVH_REQUIRE(!relu_signs || (act == MVH_ACT_RELU && Cout % 4 == 0), "cheb_conv_fwd_strided: relu_signs need act = RELU and Cout %% 4 == 0");
+  ConvIO io;
+  size_t inner = 0;
+  if (int rc = strided_setup((hipStream_t)stream, x, x_mesh_stride, x_row_stride, N, Cin, ws, ws_bytes, io, &inner)) return rc;
+  return cheb_conv_fwd_impl((hipStream_t)stream, lap, x, W, bias, out, nullptr, B, N, Cin, Cout, K, act, ws, inner, nullptr,
+                            nullptr, nullptr, relu_signs, nullptr, io);
+}
+
+extern "C" int mvh_cheb_conv_bwd_strided(mvh_stream_t stream, const mvh_csr_t* lap, const mvh_csr_t* lap_t, const float* x,
+                                         int64_t x_mesh_stride, int64_t x_row_stride, const float* W, const float* out,
+                                         const uint8_t* relu_signs, const float* dout, float* dx, float* dW, float* db,
+                                         int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K, int32_t act, void* ws,
+                                         size_t ws_bytes) {
+  MVH_REQUIRE(!relu_signs || (act == MVH_ACT_RELU && Cout % 4 == 0), "cheb_conv_bwd_strided: relu_signs need act = RELU and Cout %% 4 == 0");
+  ConvIO io;
+  size_t inner = 0;
+  if (int rc = strided_setup((hipStream_t)stream, x, x_mesh_stride, x_row_stride, N, Cin, ws, ws_bytes, io, &inner)) return rc;
+  return cheb_conv_bwd_impl((hipStream_t)stream, lap, lap_t, x, W, out, dout, nullptr, dx, dW, db, B, N, Cin, Cout, K, act,
+                            ws, inner, nullptr, nullptr, nullptr, relu_signs, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                            nullptr, io);
 }

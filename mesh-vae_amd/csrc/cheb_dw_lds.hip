@@ -679,7 +679,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
                     const uint8_t* out_bits, DwReduceEntry* defer, bool x_bf16, bool dout_bf16, const ConvIO* src3) {
   *handled = false;
-  if (src3 && !src3->src3_g) src3 = nullptr;
+  if (src3 && !src3->src3_g && !src3->x_map) src3 = nullptr;
   if (dbg().force_generic) return MVH_OK;
   if (x_bf16 && dout_bf16 && !dout_map && bstride == 0 && (out_bits || !out_mask)) {
     // the 5k level's 16 -> 16 layer on bf16 rows: packed registers, contraction on the bf16 matrix pipe
@@ -726,10 +726,17 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   d.bs = bstride > 0 ? bstride : N;
   d.map_side = dout_map ? (p_is_x ? 2 : 1) : 0;  // dout is Q when x runs the recurrence, else P
   d.map_bs = dout_rows;
+  if (src3 && src3->x_map) {  // strided x (ConvIO::x_map): the ONE row map of the kernel goes to x's side
+    if (dout_map || bstride != 0 || x_bf16 || src3->src3_g)
+      return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: a strided x beside another row map / sub-problem / bf16 rows");
+    d.map_side = p_is_x ? 1 : 2;
+    d.map_bs = src3->x_bs;
+    dout_map = src3->x_map;   // (p_map of the launch below)
+  }
   d.p_bf16 = (p_is_x ? x_bf16 : dout_bf16) ? 1 : 0;
   d.q_bf16 = (p_is_x ? dout_bf16 : x_bf16) ? 1 : 0;
   d.src3_n = 0; d.src3_c = 0;
-  if (src3) {  // lazy dout rows: the 5k level's fp32 16 -> 16 kernel with the recurrence on dout only
+  if (src3 && src3->src3_g) {  // lazy dout rows: the 5k level's fp32 16 -> 16 kernel with the recurrence on dout only
     const bool ok = !p_is_x && CQ == 16 && CP == 16 && vpt == 10 && threads == 512 && !dout_bf16 && !dout_map && bstride == 0 &&
                     (!out_mask || out_bits) && src3->src3_w && src3->src3_c == 3 && src3->src3_n >= 1 &&
                     src3->src3_n <= 512;
@@ -744,7 +751,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (NS == 1 && CQ % 4 == 0 && CQ >= 8) rc = launch_dw_cq<4>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);  // Q-split
   else if (CQ == 8) rc = launch_dw_cq<8>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
   else if (CQ == 16) rc = launch_dw_cq<16>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map, src3 ? src3->src3_g : nullptr,
-                                           src3 ? src3->src3_w : nullptr);
+                                           (src3 && src3->src3_g) ? src3->src3_w : nullptr);
   else rc = launch_dw_cq<32>(st, P, Pm, Q, Qm, lap, part, d, vpt, threads, dout_map);
   if (rc < 0) return fail(MVH_ERR_UNSUPPORTED, "cheb_dw_lds: no kernel for vpt=%d threads=%d", vpt, threads);
   if (rc) return rc;

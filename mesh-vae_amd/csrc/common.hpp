@@ -241,6 +241,13 @@ struct ConvIO {
   const float* src3_g = nullptr;
   const float* src3_w = nullptr;
   int src3_n = 0, src3_c = 0;
+  // Strided input x of a module-level call (mvh_cheb_conv_*_strided, SURVEY 8(b): the reference hands [N, B, C]-physical
+  // views around, nn/conv.py:560): row v of mesh b starts at  x + (b * x_bs + x_map[v]) * Cin  -- x_bs = mesh stride / Cin,
+  // x_map[v] = v * row stride / Cin (device int32 [N]).  The LDS-resident kernels read it through the row map and the
+  // rows-per-mesh parameter they already have (the fused un-pooling's), with no copy; every other path refuses
+  // (MVH_ERR_UNSUPPORTED, the caller copies).  Not part of any(): the elements are fp32.
+  const int32_t* x_map = nullptr;
+  int x_bs = 0;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?

@@ -23,6 +23,10 @@ class MeshVaeHipError(RuntimeError):
     pass
 
 
+class MeshVaeHipUnsupported(MeshVaeHipError):
+    """MVH_ERR_UNSUPPORTED: the call is valid but no kernel takes this shape / layout (nothing was written)."""
+
+
 class CsrStruct(ctypes.Structure):
     """mvh_csr_t"""
     _fields_ = [("n_rows", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("nnz", ctypes.c_int32),
@@ -71,6 +75,10 @@ SIGNATURES = {
     "mvh_cheb_conv_bwd_signs": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 8 + [_I] * 5 + [_P, _Z]),
     "mvh_cheb_conv_fwd_bf16": (ctypes.c_int, [_P, _CSR, _P, _P, _P, _P, _P] + [_I] * 6 + [_P, _Z]),
     "mvh_cheb_conv_bwd_bf16": (ctypes.c_int, [_P, _CSR, _CSR] + [_P] * 7 + [_I] * 6 + [_P, _Z]),
+    "mvh_cheb_conv_strided_ws_bytes": (_Z, [_I] * 5),
+    "mvh_cheb_conv_fwd_strided": (ctypes.c_int, [_P, _CSR, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 6 + [_P, _Z]),
+    "mvh_cheb_conv_bwd_strided": (ctypes.c_int, [_P, _CSR, _CSR, _P, ctypes.c_int64, ctypes.c_int64] + [_P] * 7 + [_I] * 6 + [_P, _Z]),
+    "mvh_pool_fwd_strided": (ctypes.c_int, [_P, _CSR, _P, ctypes.c_int64, ctypes.c_int64, _P, _I, _I]),
     "mvh_linear_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F]),
     "mvh_linear_bwd": (ctypes.c_int, [_P] * 8 + [_I] * 4 + [_F, _P, _Z]),
     "mvh_vae_latent_fwd": (ctypes.c_int, [_P, _P, _P, _P, _F] + [_P] * 12 + [_I] * 4),
@@ -125,7 +133,8 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise MeshVaeHipError(f"libmeshvae_hip error {rc}: {lib().mvh_last_error().decode()}")
+        cls = MeshVaeHipUnsupported if rc == 3 else MeshVaeHipError
+        raise cls(f"libmeshvae_hip error {rc}: {lib().mvh_last_error().decode()}")
 
 
 class debug_switch:

@@ -6,7 +6,7 @@ analytic backward the reference leaves to autograd.  No torch arithmetic happens
 """
 import torch
 
-from . import check, lib
+from . import MeshVaeHipUnsupported, check, lib
 
 _ws = {}
 
@@ -33,6 +33,24 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+def _row_view(x, channels_multiple=True):
+    """(mesh stride, row stride) in elements if the [B, N, C] tensor x can cross the boundary WITHOUT a copy through the
+    strided entry points (include/meshvae_hip.h: channel stride 1, positive strides that are multiples of C, 16-byte
+    aligned rows), None if it is contiguous already or does not qualify (the caller then makes the contiguous copy).
+    The reference's own modules produce exactly such views: x.transpose(0, 1) of an [N, B, C] tensor (nn/conv.py:560)."""
+    if x.dim() != 3 or x.is_contiguous():
+        return None
+    B, N, C = x.shape
+    sb, sv, sc = x.stride()
+    if sc != 1 or sb <= 0 or sv <= 0 or B == 0 or N == 0:
+        return None
+    if channels_multiple and (sb % C or sv % C):
+        return None
+    if x.data_ptr() % 16 or (C % 4 == 0 and (sb % 4 or sv % 4)):
+        return None
+    return sb, sv
+
+
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream); kernels using it are stream-ordered."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -50,9 +68,11 @@ class PoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op):
         _need_gpu(x)
-        x = x.contiguous()
         if x.dim() != 3:
             raise ValueError("SurfacePool expects x of shape [B, N, C]")
+        view = _row_view(x, channels_multiple=False)      # e.g. the transpose of an [N, B, C] tensor: read in place
+        if view is None:
+            x = x.contiguous()
         B, N, C = x.shape
         if N != op.n_in:
             # same check and message as MessagePassing.__set_size__ (nn/conv.py:165-169)
@@ -60,7 +80,10 @@ class PoolFn(torch.autograd.Function):
                              f"but expected size {op.n_in}.")
         y = torch.empty(B, op.n_out, C, dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            check(lib().mvh_pool_fwd(_stream(x), op.fwd.ref, x.data_ptr(), y.data_ptr(), B, C))
+            if view is not None:
+                check(lib().mvh_pool_fwd_strided(_stream(x), op.fwd.ref, x.data_ptr(), view[0], view[1], y.data_ptr(), B, C))
+            else:
+                check(lib().mvh_pool_fwd(_stream(x), op.fwd.ref, x.data_ptr(), y.data_ptr(), B, C))
         ctx.op = op
         return y
 
@@ -82,9 +105,9 @@ class ChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, op, act):
         _need_gpu(x, weight, bias)
-        x, weight, bias = x.contiguous(), weight.contiguous(), _c(bias)
         if x.dim() != 3:
             raise ValueError("ChebConv_batch expects x of shape [B, N, C_in]")
+        weight, bias = weight.contiguous(), _c(bias)
         B, N, Cin = x.shape
         K, Cin_w, Cout = weight.shape
         if Cin != Cin_w:
@@ -94,25 +117,40 @@ class ChebConvFn(torch.autograd.Function):
                              f"but expected size {op.n_out}.")
         out = torch.empty(B, N, Cout, dtype=x.dtype, device=x.device)
         L = lib()
-        with torch.cuda.device(x.device):
-            tx = None
-            ws = None
-            ws_bytes = 0
-            if K > 1:
-                # no T_k stack is saved: the fused kernels recompute the recurrence on chip
-                ws_bytes = L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K)
+        signs = None
+        if act and Cout % 4 == 0 and K > 1:
+            # fused ReLU: keep its signs as one byte per 4 channels, the backward reads those
+            signs = torch.empty(B, N, Cout // 4, dtype=torch.uint8, device=x.device)
+        # A non-contiguous x whose rows are intact (x.transpose(0, 1) of an [N, B, C] tensor, a batch slice, ...) is read
+        # in place by the LDS-resident kernels; shapes they do not cover answer "unsupported" and take the copy below.
+        view = _row_view(x) if K > 1 else None
+        if view is not None:
+            with torch.cuda.device(x.device):
+                ws_bytes = L.mvh_cheb_conv_strided_ws_bytes(B, N, Cin, Cout, K)
                 ws = workspace(ws_bytes, x.device)
-            signs = None
-            if act and Cout % 4 == 0 and K > 1:
-                # fused ReLU: keep its signs as one byte per 4 channels, the backward reads those
-                signs = torch.empty(B, N, Cout // 4, dtype=torch.uint8, device=x.device)
-                check(L.mvh_cheb_conv_fwd_signs(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
-                                                out.data_ptr(), signs.data_ptr(), B, N, Cin, Cout, K, _ptr(ws), ws_bytes))
-            else:
-                check(L.mvh_cheb_conv_fwd(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
-                                          out.data_ptr(), _ptr(tx), B, N, Cin, Cout, K, act, _ptr(ws), ws_bytes))
-        ctx.op, ctx.act, ctx.has_bias = op, act, bias is not None
-        ctx.save_for_backward(x, weight, out if act else None, tx, signs)
+                try:
+                    check(L.mvh_cheb_conv_fwd_strided(_stream(x), op.fwd.ref, x.data_ptr(), view[0], view[1], weight.data_ptr(),
+                                                      _ptr(bias), out.data_ptr(), _ptr(signs), B, N, Cin, Cout, K, act,
+                                                      ws.data_ptr(), ws_bytes))
+                except MeshVaeHipUnsupported:
+                    view = None
+        if view is None:
+            x = x.contiguous()
+            with torch.cuda.device(x.device):
+                ws = None
+                ws_bytes = 0
+                if K > 1:
+                    # no T_k stack is saved: the fused kernels recompute the recurrence on chip
+                    ws_bytes = L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K)
+                    ws = workspace(ws_bytes, x.device)
+                if signs is not None:
+                    check(L.mvh_cheb_conv_fwd_signs(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                                    out.data_ptr(), signs.data_ptr(), B, N, Cin, Cout, K, _ptr(ws), ws_bytes))
+                else:
+                    check(L.mvh_cheb_conv_fwd(_stream(x), op.fwd.ref, x.data_ptr(), weight.data_ptr(), _ptr(bias),
+                                              out.data_ptr(), None, B, N, Cin, Cout, K, act, _ptr(ws), ws_bytes))
+        ctx.op, ctx.act, ctx.has_bias, ctx.view = op, act, bias is not None, view
+        ctx.save_for_backward(x, weight, out if act else None, None, signs)
         return out
 
     @staticmethod
@@ -122,21 +160,34 @@ class ChebConvFn(torch.autograd.Function):
         dout = dout.contiguous()
         B, N, Cin = x.shape
         K, _, Cout = weight.shape
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(B, N, Cin, dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(weight)
         db = torch.empty(Cout, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         L = lib()
-        with torch.cuda.device(x.device):
-            ws_bytes = L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K)
-            ws = workspace(ws_bytes, x.device)
-            if signs is not None:
-                check(L.mvh_cheb_conv_bwd_signs(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
-                                                out.data_ptr(), signs.data_ptr(), dout.data_ptr(), _ptr(dx),
-                                                dW.data_ptr(), _ptr(db), B, N, Cin, Cout, K, ws.data_ptr(), ws_bytes))
-            else:
-                check(L.mvh_cheb_conv_bwd(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
-                                          _ptr(out), dout.data_ptr(), _ptr(tx), _ptr(dx), dW.data_ptr(), _ptr(db),
-                                          B, N, Cin, Cout, K, act, ws.data_ptr(), ws_bytes))
+        view = ctx.view
+        if view is not None:                    # the saved x is the caller's strided view: the dW kernel reads it in place
+            with torch.cuda.device(x.device):
+                ws_bytes = L.mvh_cheb_conv_strided_ws_bytes(B, N, Cin, Cout, K)
+                ws = workspace(ws_bytes, x.device)
+                try:
+                    check(L.mvh_cheb_conv_bwd_strided(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), view[0], view[1],
+                                                      weight.data_ptr(), _ptr(out), _ptr(signs), dout.data_ptr(), _ptr(dx),
+                                                      dW.data_ptr(), _ptr(db), B, N, Cin, Cout, K, act, ws.data_ptr(), ws_bytes))
+                except MeshVaeHipUnsupported:
+                    view = None
+        if view is None:
+            x = x.contiguous()
+            with torch.cuda.device(x.device):
+                ws_bytes = L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K)
+                ws = workspace(ws_bytes, x.device)
+                if signs is not None:
+                    check(L.mvh_cheb_conv_bwd_signs(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
+                                                    out.data_ptr(), signs.data_ptr(), dout.data_ptr(), _ptr(dx),
+                                                    dW.data_ptr(), _ptr(db), B, N, Cin, Cout, K, ws.data_ptr(), ws_bytes))
+                else:
+                    check(L.mvh_cheb_conv_bwd(_stream(x), op.fwd.ref, op.bwd.ref, x.data_ptr(), weight.data_ptr(),
+                                              _ptr(out), dout.data_ptr(), _ptr(tx), _ptr(dx), dW.data_ptr(), _ptr(db),
+                                              B, N, Cin, Cout, K, act, ws.data_ptr(), ws_bytes))
         return dx, dW, db, None, None
 
 
