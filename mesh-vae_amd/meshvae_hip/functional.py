@@ -79,6 +79,9 @@ class PoolFn(torch.autograd.Function):
             raise ValueError(f"Encountered node tensor with size {N} in dimension 0, "
                              f"but expected size {op.n_in}.")
         y = torch.empty(B, op.n_out, C, dtype=x.dtype, device=x.device)
+        ctx.op = op
+        if B == 0:
+            return y
         with torch.cuda.device(x.device):
             if view is not None:
                 check(lib().mvh_pool_fwd_strided(_stream(x), op.fwd.ref, x.data_ptr(), view[0], view[1], y.data_ptr(), B, C))
@@ -93,6 +96,8 @@ class PoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, _, C = dy.shape
         dx = torch.empty(B, op.n_in, C, dtype=dy.dtype, device=dy.device)
+        if B == 0:
+            return dx, None
         with torch.cuda.device(dy.device):
             check(lib().mvh_pool_bwd(_stream(dy), op.bwd.ref, dy.data_ptr(), dx.data_ptr(), B, C))
         return dx, None
@@ -124,6 +129,10 @@ class ChebConvFn(torch.autograd.Function):
         # A non-contiguous x whose rows are intact (x.transpose(0, 1) of an [N, B, C] tensor, a batch slice, ...) is read
         # in place by the LDS-resident kernels; shapes they do not cover answer "unsupported" and take the copy below.
         view = _row_view(x) if K > 1 else None
+        if B == 0:                              # an empty batch (empty tensors have no address): nothing to launch
+            ctx.op, ctx.act, ctx.has_bias, ctx.view = op, act, bias is not None, None
+            ctx.save_for_backward(x, weight, out if act else None, None, signs)
+            return out
         if view is not None:
             with torch.cuda.device(x.device):
                 ws_bytes = L.mvh_cheb_conv_strided_ws_bytes(B, N, Cin, Cout, K)
@@ -165,6 +174,8 @@ class ChebConvFn(torch.autograd.Function):
         db = torch.empty(Cout, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         L = lib()
         view = ctx.view
+        if B == 0:                              # empty batch: empty dx, zero parameter gradients (a sum over no meshes)
+            return dx, dW.zero_(), (db.zero_() if db is not None else None), None, None
         if view is not None:                    # the saved x is the caller's strided view: the dW kernel reads it in place
             with torch.cuda.device(x.device):
                 ws_bytes = L.mvh_cheb_conv_strided_ws_bytes(B, N, Cin, Cout, K)
