@@ -282,3 +282,20 @@ def test_b64_equals_eight_b8_runs_bitwise(which):
         _, part = _native(net, b, x[sl].contiguous(), y[sl].contiguous(), eps[sl].contiguous(), du)
         for k in ("recon", "z", "y_hat", "kld", "rec"):
             assert torch.equal(part[k], full[k][sl]), (k, c)
+
+
+@pytest.mark.parametrize("B", [1, 7, 63, 65])
+def test_ragged_batch_sizes_match_oracle(B):
+    """Batches that are not multiples of the 8 XCDs (the block -> mesh maps end in `if (mesh >= B) return`), a single
+    mesh, and one mesh more than the benchmarked batch: the whole fp32 step against the oracle, all meshes, same bars."""
+    dev = _dev()
+    net = _build(CFG_5K, "topology_5k.npz", dev).train()
+    x, y, eps, g = _inputs(net, B, seed=40 + B)
+    H, flat = net.num_hidden, net.dec_lin_2.out_features
+    drop_u = torch.rand(B * (3 * H + flat), generator=g)
+    nat, got = _native(net, B, x, y, eps, drop_u)
+    want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat)
+    pins = _relu_ties(nat, net, want, drop_u, f"b{B} fp32 5k", "topology_5k.npz")
+    if pins:
+        want = _oracle(CFG_5K, "topology_5k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
+    _compare_with_oracle(got, want, f"b{B} fp32 5k")
