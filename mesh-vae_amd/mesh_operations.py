@@ -83,9 +83,10 @@ def numpy_cblas():
         try:
             from threadpoolctl import threadpool_info
             np.dot(np.ones((1, 2)), np.ones((2, 2)))            # (makes sure the BLAS is loaded)
-            for info in threadpool_info():
-                if info.get("user_api") != "blas":
-                    continue
+            # numpy's own BLAS first (scipy ships another OpenBLAS build; np.dot never goes through that one)
+            blas_libs = [i for i in threadpool_info() if i.get("user_api") == "blas" and i.get("filepath")]
+            blas_libs.sort(key=lambda i: 0 if "numpy" in i["filepath"] else 1)
+            for info in blas_libs:
                 handle = ctypes.CDLL(info["filepath"])
                 for pre, suf, ilp64 in (("scipy_", "64_", 1), ("", "64_", 1), ("scipy_", "", 0), ("", "", 0)):
                     try:
