@@ -363,16 +363,17 @@ def capture_inference(fn, x, dev):
     return g, out
 
 
-def run_infer(args, dev, emit):
-    """BASELINE configs[4]: hipGraph-captured inference latency at B = 1 / 32 / 256 through the reference-API module."""
+def infer_latencies(dev, steps, warmup):
+    """(hipGraph replay, eager) latency in ms of encode + classify + 2 x decode at B = 1 / 32 / 256; the replay is checked
+    bitwise against the eager result."""
     net = build_model(dev).eval()
     fn = estimate_diff_fn(net)
     lat, eager = {}, {}
-    iters = max(args.steps, 20)
+    iters = max(steps, 20)
     for B in (1, 32, 256):
         x = torch.randn(B, 4998, 3, device=dev)
         with torch.no_grad():
-            for _ in range(max(args.warmup, 3)):
+            for _ in range(max(warmup, 3)):
                 ref = fn(x)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -385,7 +386,7 @@ def run_infer(args, dev, emit):
             torch.cuda.synchronize(dev)
             for a, b in zip(out, ref):
                 assert torch.equal(a, b), "hipGraph replay differs from the eager result"
-            for _ in range(max(args.warmup, 3)):
+            for _ in range(max(warmup, 3)):
                 g.replay()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -393,6 +394,12 @@ def run_infer(args, dev, emit):
                 g.replay()
             torch.cuda.synchronize(dev)
             lat[B] = (time.perf_counter() - t0) / iters * 1e3
+    return net, lat, eager, iters
+
+
+def run_infer(args, dev, emit):
+    """BASELINE configs[4]: hipGraph-captured inference latency at B = 1 / 32 / 256 through the reference-API module."""
+    net, lat, eager, iters = infer_latencies(dev, args.steps, args.warmup)
     out = {"metric": "inference latency (encode + classify + 2 x decode, hipGraph replay), 5k-vertex ChebConv VAE, batch 32",
            "value": lat[32], "unit": "ms", "n_gpus": 1, "steps": iters, "warmup": max(args.warmup, 3),
            "ms_per_step": lat[32], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -581,6 +588,12 @@ def main():
                 "bf16": timed_variant(dev, "train5k", "bf16", B, args.steps, args.warmup, min(prewarm, 100), args.seed),
                 "hires20k": timed_variant(dev, "hires20k", "f32", B, max(10, args.steps // 2), max(3, args.warmup // 2), 20,
                                           args.seed)}
+            # ... and configs[4] (inference, hipGraph replay): the latencies of `--config infer`
+            _, lat, eager, it = infer_latencies(dev, max(20, args.steps), max(3, args.warmup // 2))
+            out["variants"]["infer"] = {"workload": WORKLOADS["infer"], "unit": "ms", "steps": it,
+                                        "latency_ms": {f"b{b}": lat[b] for b in lat},
+                                        "eager_latency_ms": {f"b{b}": eager[b] for b in eager},
+                                        "replay_equals_eager_bitwise": True}
         emit(out)
     if dist.is_initialized():
         dist.barrier()

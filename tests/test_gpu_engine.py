@@ -669,11 +669,14 @@ def test_bench_line_contract():
     assert len(d["kernels"]) == 25                       # 9 conv layers x (fwd, dX, dW) minus the first layer's dX and dW
     # the other configurations, driver-timed by the same process after the headline's timed region
     v = d["variants"]
-    assert set(v) == {"bf16", "hires20k"}
+    assert set(v) == {"bf16", "hires20k", "infer"}
     assert v["bf16"]["dtype"] == "bf16" and v["bf16"]["workload"].startswith("configs[1]") and v["bf16"]["steps"] == 5
     assert v["hires20k"]["workload"].startswith("configs[3]") and v["hires20k"]["value"] > 0
-    for leg in v.values():
+    for leg in (v["bf16"], v["hires20k"]):
         assert abs(leg["value"] - 64 * 1e3 / leg["ms_per_step"]) < 1e-6 * leg["value"] and 0 < leg["step_roofline"]["frac"] < 1
+    # configs[4]: the three hipGraph replay latencies (ms), replay checked bitwise against eager inside the bench
+    assert v["infer"]["workload"].startswith("configs[4]") and v["infer"]["replay_equals_eager_bitwise"] is True
+    assert set(v["infer"]["latency_ms"]) == {"b1", "b32", "b256"} and all(0 < t < 50 for t in v["infer"]["latency_ms"].values())
 
 
 def test_bench_infer_line_contract():
