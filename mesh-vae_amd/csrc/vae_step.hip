@@ -173,6 +173,15 @@ static SideStream* side_for_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream& s = side[dev];
   if (!s.stream) {
+    // Fork / join events between the caller's stream and the two gradient lanes order work on ONE device: they do not need
+    // the system-scope fence hipEventRecord performs by default (cache write-back and invalidation for the host and other
+    // devices; hip_runtime_api.h: "may improve performance but device memory may not be visible to the host and other
+    // devices").  Whatever leaves the device is behind the caller's own stream synchronisation / events.  MEASURED:
+    // 524.2 against 535.0 us per step (profiles/r03_ab_evflags.txt); -DMVH_EV_FLAGS=0 restores the default events.
+#ifndef MVH_EV_FLAGS
+#define MVH_EV_FLAGS hipEventDisableSystemFence
+#endif
+    constexpr unsigned kEvFlags = MVH_EV_FLAGS;
     // debug switch side_prio = -1 / +1: queue priority of the two weight-gradient lanes relative to the caller's stream
     int lo = 0, hi = 0, prio = 0;
     const int pe = dbg().side_prio;
@@ -180,9 +189,9 @@ static SideStream* side_for_device() {
     if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     if (hipStreamCreateWithPriority(&s.dense, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
-      if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.tstack_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.tstack_done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
     s.n_ev = 64;
   }
   return &s;
