@@ -9,6 +9,7 @@ gradients live in two contiguous buffers so no bucketing copies exist; `dec_lin_
 used, cheb_VAE.py:165) stays in the buffers with a zero gradient.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -275,7 +276,8 @@ class TrainStep:
         nat, st = self.native[j], self.streams[j][0]
         mb = self.B // self.n_micro
         sl = slice(j * mb, (j + 1) * mb)
-        eps = self.eps[sl] if self.m_type == "train" else None
+        src = self._eps_view if getattr(self, "_eps_view", None) is not None else self.eps
+        eps = src[sl] if self.m_type == "train" else None
         with torch.cuda.device(self.dev), torch.cuda.stream(st if st is not None else cur):
             return nat.forward_backward(self.x[sl], self.x_gt[sl], self.y[sl], eps, u)
 
@@ -358,12 +360,44 @@ class TrainStep:
                     bufs.append(view)
             self._u_bufs = bufs
 
+    E_AHEAD = 16     # eager, private host generator: steps' worth of reparameterisation noise per pinned copy
+
+    def _eps_ahead(self):
+        """Draw-ahead is only the same noise when nobody else draws from the generator in between: the step's PRIVATE host
+        generator (noise_seed given), never the process default one (the reference's behaviour, cheb_VAE.py:316); and only
+        where eps is passed per call (eager native chains; a hipGraph reads the static buffer)."""
+        return (self.host_gen is not None and self.native is not None and not self.use_graph and
+                os.environ.get("MESHVAE_EPS_AHEAD", "1") != "0")
+
     def _draw_eps(self):
         """Reparameterisation noise from the HOST default generator (reference cheb_VAE.py:316), moved
         with an asynchronous copy from a small ring of pinned buffers so the host never blocks on
         the device (a pageable .to(device) would serialise host and GPU every step)."""
         if self.m_type != "train":
             return
+        if self._eps_ahead():
+            # Private host generator, eager native step: the noise of E_AHEAD steps is drawn in one go -- the SAME
+            # torch.normal calls in the same order, so every step sees the numbers it would have drawn itself -- and moved
+            # by ONE pinned copy per E_AHEAD steps; a step's eps is a view of the device block.  (The per-step form costs a
+            # host-to-device copy and an event record -- both system-scope operations -- on the critical chain of every step.)
+            E = self.E_AHEAD
+            if not hasattr(self, "_eps_blocks"):
+                self._eps_blocks = [(torch.empty(E, self.B, self.net.z).pin_memory(), torch.cuda.Event(),
+                                     torch.empty(E, self.B, self.net.z, device=self.dev)) for _ in range(2)]
+                self._eps_blk_i, self._eps_left, self._eps_block = 0, 0, None
+            if self._eps_left == 0:
+                host, ev, devb = self._eps_blocks[self._eps_blk_i]
+                self._eps_blk_i ^= 1
+                ev.synchronize()                           # the copy that read this pinned block 2 E_AHEAD steps ago
+                for i in range(E):
+                    torch.normal(mean=0, std=1, size=(self.B, self.net.z), out=host[i], generator=self.host_gen)
+                devb.copy_(host, non_blocking=True)        # (stream-ordered behind every step that read this device block)
+                ev.record(torch.cuda.current_stream(self.dev))
+                self._eps_block, self._eps_left = devb, E
+            self._eps_view = self._eps_block[E - self._eps_left]
+            self._eps_left -= 1
+            return
+        self._eps_view = None
         if not hasattr(self, "_eps_ring"):
             self._eps_ring = [(torch.empty(self.B, self.net.z).pin_memory(), torch.cuda.Event()) for _ in range(8)]
             self._eps_i = 0
