@@ -98,6 +98,7 @@ struct DebugCfg {
   int tail_main = 0;       // 1: encoder layer 1's dW runs on the main stream after layer 0's (round 1's choice; since the
                            //    deferred reductions emptied the side lane's backlog the lane is the faster place: 570 vs 576 us)
   int fork_batch = 1;      // conv layers sharing one fork event (1..4)
+  int fork_small = 400;    // with fork_batch = 1: layers of at most this many vertices share a fork in pairs (0: never)
   int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
   int no_dw_mfma = 0;
   int no_xcd_remap = 0;    // k_spmm tiles without the mesh -> XCD mapping

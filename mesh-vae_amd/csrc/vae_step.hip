@@ -568,6 +568,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     }
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
                                      dout_pool, unpool_t, unpooled, tx, io};
+    // A fork is an event record between two kernels of the critical chain: 3.5 us of that chain.  The weight
+    // gradients of the coarse levels (<= fork_small vertices, default 400: two 17 us kernels at 79 / 313 vertices) are short
+    // enough to wait for the next layer's fork: two such layers share one.  MEASURED: 515-517 against 521-526 us per step;
+    // with the 1250-vertex level in the scheme (fork_small = 1300) 526-531, with three layers per fork 541.
+    if (fork_batch == 1 && N <= dbg().fork_small && n_pending < 2) return MVH_OK;
     if (n_pending >= fork_batch) return flush_dw(false);
     return MVH_OK;
   };

@@ -721,6 +721,7 @@ def test_round3_forms_against_their_debug_switches(B):
                 {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     base_out, base_g = run(None)
     for switch, exact in ((("keep_enc_out", 1), True), (("no_final_fuse", 1), True), (("tstack_tall", 1), True),
+                          (("fork_small", 0), True),        # (every coarse layer's weight gradient behind a fork of its own)
                           (("no_src3", 1), False), (("dw_tie_x", 1), False)):
         out, grads = run(switch)
         for k in base_out:
