@@ -572,7 +572,11 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     // gradients of the coarse levels (<= fork_small vertices, default 400: two 17 us kernels at 79 / 313 vertices) are short
     // enough to wait for the next layer's fork: two such layers share one.  MEASURED: 515-517 against 521-526 us per step;
     // with the 1250-vertex level in the scheme (fork_small = 1300) 526-531, with three layers per fork 541.
+    // The final layer's three short launches wait for the last decoder stage's fork: 512.6-513.4 against 515.8-518.4 us.
+    // (Letting the decoder's coarse layers wait for the dense head's fork behind them as well: 540-545 -- the lane IS the
+    //  tail of the step.)
     if (fork_batch == 1 && N <= dbg().fork_small && n_pending < 2) return MVH_OK;
+    if (fork_batch == 1 && dbg().fork_small > 0 && act == MVH_ACT_NONE && cout <= 4 && n_pending < 2) return MVH_OK;
     if (n_pending >= fork_batch) return flush_dw(false);
     return MVH_OK;
   };
