@@ -36,6 +36,7 @@ struct DwDims {
   int ovf;                                 // MVH_CSR_ELL_OVERFLOW: rows longer than 8 continue in the CSR columns
   int p_bf16, q_bf16;                      // the P / Q tensor is stored as bf16 (bf16.hpp); masks are sign bytes then
   int src3_n, src3_c;                      // > 0: P rows >= src3_n are p_g3[v][0..src3_c) W3^T (ConvIO::src3_*; P = dout, fp32)
+  int mesh0;                               // first mesh of this launch (ConvIO::dw_split: the batch in several launches)
 };
 
 __device__ __forceinline__ void add4f(float4& a, const float4& b) {
@@ -94,7 +95,7 @@ k_cheb_dw_lds(const float* __restrict__ p_P, const float* __restrict__ p_Pmask, 
   const int QP = SPLIT ? a.CQtot / 4 : 1, CQT = SPLIT ? a.CQtot : CQ;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int per_mesh = NS * QP, rem = jj % per_mesh;
-  const int mesh = (jj / per_mesh) * 8 + xcd, sl = rem / QP, s0 = sl * 4, q0 = 4 * (rem % QP);
+  const int mesh = a.mesh0 + (jj / per_mesh) * 8 + xcd, sl = rem / QP, s0 = sl * 4, q0 = 4 * (rem % QP);
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6;
   MVH_STAMPX(0);
@@ -643,9 +644,17 @@ static int launch_dw_one(hipStream_t st, const float* P, const float* Pm, const 
   static LdsAttr attr;
   if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int NS = (d.CP + 3) / 4, QP = (CQ == 4) ? d.CQtot / 4 : 1;
-  const int grid = ((d.B + 7) / 8) * 8 * NS * QP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, g3, w3, d);
-  MVH_LAUNCH_CHECK();
+  // d.mesh0 < 0: the batch in -mesh0 launches of whole 8-mesh groups, one behind the other on this stream (ConvIO::dw_split)
+  const int split = d.mesh0 < 0 ? -d.mesh0 : 1;
+  const int per = ((((d.B + split - 1) / split) + 7) / 8) * 8;
+  for (int m0 = 0; m0 < d.B; m0 += per) {
+    DwDims dd = d;
+    dd.mesh0 = m0;
+    const int nb = d.B - m0 < per ? d.B - m0 : per;
+    const int grid = ((nb + 7) / 8) * 8 * NS * QP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Pm, Q, Qm, lap->rowinfo, lap->ell, part, map, lap->col, g3, w3, dd);
+    MVH_LAUNCH_CHECK();
+  }
   return MVH_OK;
 }
 
@@ -679,6 +688,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
                     bool* handled, int bstride, const int32_t* dout_map, int dout_rows, bool dry_run,
                     const uint8_t* out_bits, DwReduceEntry* defer, bool x_bf16, bool dout_bf16, const ConvIO* src3) {
   *handled = false;
+  const int dw_split = src3 ? src3->dw_split : 1;
   if (src3 && !src3->src3_g && !src3->x_map) src3 = nullptr;
   if (dbg().force_generic) return MVH_OK;
   if (x_bf16 && dout_bf16 && !dout_map && bstride == 0 && (out_bits || !out_mask)) {
@@ -736,6 +746,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   d.p_bf16 = (p_is_x ? x_bf16 : dout_bf16) ? 1 : 0;
   d.q_bf16 = (p_is_x ? dout_bf16 : x_bf16) ? 1 : 0;
   d.src3_n = 0; d.src3_c = 0;
+  d.mesh0 = (dw_split > 1 && vpt == 10) ? -dw_split : 0;
   if (src3 && src3->src3_g) {  // lazy dout rows: the 5k level's fp32 16 -> 16 kernel with the recurrence on dout only
     const bool ok = !p_is_x && CQ == 16 && CP == 16 && vpt == 10 && threads == 512 && !dout_bf16 && !dout_map && bstride == 0 &&
                     (!out_mask || out_bits) && src3->src3_w && src3->src3_c == 3 && src3->src3_n >= 1 &&

@@ -98,6 +98,8 @@ struct DebugCfg {
   int tail_main = 0;       // 1: encoder layer 1's dW runs on the main stream after layer 0's (round 1's choice; since the
                            //    deferred reductions emptied the side lane's backlog the lane is the faster place: 570 vs 576 us)
   int fork_batch = 1;      // conv layers sharing one fork event (1..4)
+  int l0_lane = 2;         // level-0 weight gradient on the dense lane, behind the level-0 dX, in this many launches (0: conv lane, one launch)
+  int l0_hold = 1;         // ... behind this many further forks of the main chain
   int fork_small = 400;    // with fork_batch = 1: layers of at most this many vertices share a fork in pairs (0: never)
   int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
   int no_dw_mfma = 0;
@@ -249,6 +251,9 @@ struct ConvIO {
   // (MVH_ERR_UNSUPPORTED, the caller copies).  Not part of any(): the elements are fp32.
   const int32_t* x_map = nullptr;
   int x_bs = 0;
+  // weight gradient of the 5k level (k_cheb_dw_lds<.., 10, 512, ..>: one 160 KB workgroup per CU): the batch in dw_split
+  // launches one behind the other, so that the kernel holds 1 / dw_split of the CUs at a time (the step engine's level-0 lane)
+  int dw_split = 1;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?

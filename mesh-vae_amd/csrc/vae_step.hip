@@ -472,7 +472,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   void* ss = (char*)ws + p.scratch_side;
   // debug switch dw_lane2: the small levels' conv weight gradients alternate between the conv lane and the dense lane
   const bool lane2 = dbg().dw_lane2 && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits;
-  void* ss2 = lane2 ? (void*)((char*)ws + p.scratch_side2) : ss;
+  void* ss2 = p.scratch_side2 != kNoBits ? (void*)((char*)ws + p.scratch_side2) : ss;   // (second lane's scratch)
   int lane_toggle = 0;
   const float pd = drop_u ? d->dropout_p : 0.f;  // eval mode: no mask was applied in the forward
   const bool bf = d->storage == MVH_STORAGE_BF16;   // bf16 activations and activation gradients (see the forward)
@@ -512,26 +512,47 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     const float* tx;                        // T_k stack kept by the forward (big levels), else null
     ConvIO io;
   };
-  PendingDw pending[4];
+  PendingDw pending[6];
   int n_pending = 0;
   hipStream_t sstream_conv = sstream;
   void* ss_conv = ss;
   const int fork_batch = dbg().fork_batch < 1 ? 1 : (dbg().fork_batch > 4 ? 4 : dbg().fork_batch);
+  // The level-0 lane.  The 5k level's weight-gradient kernel is one 160 KB workgroup per CU: as ONE launch it holds every CU
+  // for its 54 us and the main chain's next small-level kernel waits for it (timeline: 64 us for a 7 us kernel).  It is
+  // therefore held back until the fork BEHIND the level's dX kernel (chip-filling as well: side by side the two would only
+  // take turns) and then runs on the dense lane in l0_lane launches of B / l0_lane meshes, one behind the other: at most
+  // 256 / l0_lane CUs are taken at a time and the latency-bound small-level chain runs on the others.
+  const int l0_split = (!lane2 && !bf && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits && B >= 16 &&
+                        dbg().l0_lane > 1) ? dbg().l0_lane : 0;
+  PendingDw held;
+  bool have_held = false;
+  int held_forks = 0;
   auto flush_dw = [&](bool also_dense) -> int {  // one event for everything queued (+ the dense lane)
-    if (n_pending == 0 && !also_dense) return MVH_OK;
+    if (n_pending == 0 && !also_dense && !have_held) return MVH_OK;
+    const bool launch_held = have_held && (also_dense || n_pending == 0 || --held_forks <= 0);
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
       if (n_pending > 0) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
       if ((also_dense && (dstream != sstream || n_pending == 0)) || (lane2 && n_pending > 0))
         MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
+      if (launch_held && !also_dense) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
+    if (launch_held) { pending[n_pending++] = held; have_held = false; }   // (pending has room: a flush comes at two items at the latest)
     for (int q = 0; q < n_pending; ++q) {
-      const PendingDw& w = pending[q];
+      PendingDw& w = pending[q];
       bool deferred = false, fused = false;
       hipStream_t sstream = sstream_conv;      // (shadows: this item's lane)
       void* ss = ss_conv;
       if (lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1)) { sstream = dstream; ss = ss2; }
+      const bool is_l0 = l0_split && w.N + 1 > 2048 && w.N + 1 <= 5120 && w.cin == 16 && w.cout == 16 && !w.dout_pool;
+      if (is_l0 && !(launch_held && q == n_pending - 1)) {   // not yet: behind the next fork
+        held = w;
+        have_held = true;
+        held_forks = dbg().l0_hold < 1 ? 1 : dbg().l0_hold;
+        continue;
+      }
+      if (is_l0) { sstream = dstream; ss = ss2; w.io.dw_split = l0_split; }
       const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
       const float* dout = w.dout;
       if (w.dout_pool) {

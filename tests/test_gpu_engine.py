@@ -689,13 +689,15 @@ def test_bench_infer_line_contract():
     assert d["config"]["hipgraph"] is True and d["config"]["replay_equals_eager_bitwise"] is True
 
 
-@pytest.mark.parametrize("B", [5, 16])
+@pytest.mark.parametrize("B", [5, 16, 40])
 def test_round3_forms_against_their_debug_switches(B):
     """Every form this round added to the native step has a debug switch that restores the previous launch sequence; the
     step must not care: storing only what is read (keep_enc_out), the final layer's map inside the loss launch
     (no_final_fuse) and the stack kernel's shape (tstack_tall) change NOTHING, bit for bit; lazy rows between the final
     layer and the last decoder stage (no_src3) and the side the weight-gradient recurrence runs on (dw_tie_x) re-order
-    fp32 sums: gradients within 2e-5 relative, forward outputs bitwise."""
+    fp32 sums: gradients within 2e-5 relative, forward outputs bitwise.  The level-0 lane (l0_lane: the 5k level's weight
+    gradient held back behind the level's dX and cut into part-batch launches on the dense lane, B >= 16) moves launches
+    only: bitwise against the single launch and against a three-way cut (B = 40: 16 + 16 + 8 meshes)."""
     from conftest import CFG_5K
     from meshvae_hip import debug_switch
     from meshvae_hip.engine import NativeStep
@@ -722,6 +724,8 @@ def test_round3_forms_against_their_debug_switches(B):
     base_out, base_g = run(None)
     for switch, exact in ((("keep_enc_out", 1), True), (("no_final_fuse", 1), True), (("tstack_tall", 1), True),
                           (("fork_small", 0), True),        # (every coarse layer's weight gradient behind a fork of its own)
+                          (("l0_lane", 0), True),           # (the 5k level's weight gradient as ONE launch on the conv lane)
+                          (("l0_lane", 3), True),           # (... in three part-batch launches: 24 + 24 + 16 meshes)
                           (("no_src3", 1), False), (("dw_tie_x", 1), False)):
         out, grads = run(switch)
         for k in base_out:
