@@ -272,6 +272,15 @@ def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "d
     out = {"bound": "hbm", "kernel": f'{top["kernel"] or "split/stack path"}: {top["op"]}', "achieved": ach,
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": prof.get("hbm_bytes"),
            "avg_launch_us": top["ms"] * 1e3, "algorithmic_bytes_per_launch": top["bytes"], "ranking": ranking}
+    if (top["kernel"] or "").startswith(("k_cheb_dw_lds<16,10,512,4>", "k_cheb_dw_l0h")) and 32 < B <= 64 and config == "train5k":
+        # the figure above is the kernel on the whole batch in ONE launch (what the module-level op issues).  The train
+        # step issues it as two half-batch launches on the dense lane (the "level-0 lane"): the kernel is one
+        # 160 KB workgroup per CU, and on half the CUs at a time it no longer stops the small-level chain of the main
+        # stream.  rocprofv3 therefore lists 2 calls per step, each over B / 2 meshes (half the algorithmic bytes), with a
+        # duration that includes the kernels running beside it; the kernel's own speed is the isolated figure.
+        out["in_step"] = {"launches_per_step": 2, "meshes_per_launch": B // 2,
+                          "algorithmic_bytes_per_launch": top["bytes"] // 2,
+                          "note": "half-batch launches beside the main chain; rocprof avg_us is per half-batch launch, contended"}
     if rocprof_top:
         out["rocprof_top"] = {"file": f"profiles/{tag}_kernel_stats.csv", "by_total_time": rocprof_top}
     if prof:

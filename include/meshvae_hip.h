@@ -96,6 +96,7 @@ int mvh_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
 /* Debug / A-B switches (no reference counterpart).  They live in ONE struct that is filled when the
  * library is loaded from MESHVAE_DEBUG="key=value,..." and is never re-read from the environment;
  * keys: force_generic, l0_wide, side_prio, no_side, no_tstack, tail_main, fork_batch, fork_small,
+ * l0_lane, l0_lane_any, l0_lane_bf, l0_hold, enc_dense (the level-0 lane of the train step),
  * no_gstack_mfma, no_dw_mfma, no_xcd_remap, no_prefetch, no_l0h, no_head_fuse, no_big, no_dx_tstack,
  * no_dx_first, no_bwd_fused, no_dw_rows, keep_enc_out, dw_lane2, tstack_tall,
  * prefetch_at, dw_tie_x, no_src3, no_final_fuse, skip_conv_dw (timing only: results invalid), roctx (roctx ranges per layer of the step for rocprofv3 --marker-trace).  mvh_debug_set changes one switch in-process (the tests run

@@ -44,8 +44,11 @@ static const DebugKey kDebugKeys[] = {
     {"keep_enc_out", &DebugCfg::keep_enc_out},   {"dw_lane2", &DebugCfg::dw_lane2},
     {"tstack_tall", &DebugCfg::tstack_tall},     {"prefetch_at", &DebugCfg::prefetch_at},
     {"dw_tie_x", &DebugCfg::dw_tie_x},           {"roctx", &DebugCfg::roctx},
-    {"no_src3", &DebugCfg::no_src3},             {"skip_conv_dw", &DebugCfg::skip_conv_dw},             {"no_final_fuse", &DebugCfg::no_final_fuse},             {"fork_small", &DebugCfg::fork_small},             {"l0_lane", &DebugCfg::l0_lane},
-    {"l0_hold", &DebugCfg::l0_hold},
+    {"no_src3", &DebugCfg::no_src3},             {"skip_conv_dw", &DebugCfg::skip_conv_dw},
+    {"no_final_fuse", &DebugCfg::no_final_fuse}, {"fork_small", &DebugCfg::fork_small},
+    {"l0_lane", &DebugCfg::l0_lane},             {"l0_lane_any", &DebugCfg::l0_lane_any},
+    {"l0_lane_bf", &DebugCfg::l0_lane_bf},       {"l0_hold", &DebugCfg::l0_hold},
+    {"enc_dense", &DebugCfg::enc_dense},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

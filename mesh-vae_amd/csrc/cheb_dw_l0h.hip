@@ -22,6 +22,7 @@ namespace mvh {
 
 struct DwL0hDims {
   int B, N, K, bs, db_mode, has_bits;
+  int mesh0;   // first mesh of this launch (ConvIO::dw_split)
 };
 
 typedef float v4f_d __attribute__((ext_vector_type(4)));
@@ -69,7 +70,7 @@ k_cheb_dw_l0h(const uint16_t* __restrict__ p_x, const uint16_t* __restrict__ p_d
   float4* slabA = reinterpret_cast<float4*>(smem);
   float4* slabB = slabA + VS;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int mesh = (jj >> 2) * 8 + xcd, sl = jj & 3, s0 = sl * 4;
+  const int mesh = a.mesh0 + (jj >> 2) * 8 + xcd, sl = jj & 3, s0 = sl * 4;
   if (mesh >= a.B) return;
   const int tid = threadIdx.x, N = a.N, lane = tid & 63, wave = tid >> 6, qi = lane & 3;
 
@@ -217,7 +218,7 @@ size_t cheb_dw_l0h_ws_bytes(int B, int K) { return (size_t)B * 4 * (kDwhThreads 
 // dW (+ db) of the 5k level's 16 -> 16 layer on bf16 rows; *handled == false -> the caller keeps cheb_dw_lds.hip.
 int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled, bool dry_run, DwReduceEntry* defer) {
+                    bool* handled, bool dry_run, DwReduceEntry* defer, int dw_split) {
   *handled = false;
   if (dbg().force_generic || dbg().no_l0h) return MVH_OK;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
@@ -231,14 +232,21 @@ int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
     return MVH_OK;
   }
   const int NW = kDwhThreads / 64;
-  DwL0hDims d{B, N, K, N, db ? 1 : 0, out_bits ? 1 : 0};
+  DwL0hDims d{B, N, K, N, db ? 1 : 0, out_bits ? 1 : 0, 0};
   const size_t lds = (size_t)kDwhSlots * 32;
   static LdsAttr attr;
   if (int rc = attr.ensure(reinterpret_cast<const void*>(k_cheb_dw_l0h), lds)) return rc;
-  const int grid = ((B + 7) / 8) * 8 * 4;
-  hipLaunchKernelGGL(k_cheb_dw_l0h, dim3(grid), dim3(kDwhThreads), lds, st, reinterpret_cast<const uint16_t*>(x),
-                     reinterpret_cast<const uint16_t*>(dout), out_bits, lap->rowinfo, lap->ell, part, d);
-  MVH_LAUNCH_CHECK();
+  // the batch in dw_split launches of whole 8-mesh groups, one behind the other on this stream (ConvIO::dw_split)
+  const int split = dw_split > 1 ? dw_split : 1;
+  const int per = ((((B + split - 1) / split) + 7) / 8) * 8;
+  for (int m0 = 0; m0 < B; m0 += per) {
+    d.mesh0 = m0;
+    const int nb = B - m0 < per ? B - m0 : per;
+    const int grid = ((nb + 7) / 8) * 8 * 4;
+    hipLaunchKernelGGL(k_cheb_dw_l0h, dim3(grid), dim3(kDwhThreads), lds, st, reinterpret_cast<const uint16_t*>(x),
+                       reinterpret_cast<const uint16_t*>(dout), out_bits, lap->rowinfo, lap->ell, part, d);
+    MVH_LAUNCH_CHECK();
+  }
   // tile entry (q, j): q = dpre channel (co), j = x channel 4 slab + j (ci): P is x
   const DwReduceEntry ent{part, B * NW, 4, K, 16, 16, 1, Cin, Cout, db ? 1 : 0, dW, db};
   if (defer) {

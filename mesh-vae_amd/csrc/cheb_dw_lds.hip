@@ -694,7 +694,7 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
   if (x_bf16 && dout_bf16 && !dout_map && bstride == 0 && (out_bits || !out_mask)) {
     // the 5k level's 16 -> 16 layer on bf16 rows: packed registers, contraction on the bf16 matrix pipe
     if (int rc = try_cheb_dw_l0h(st, lap, x, dout, Cout % 4 == 0 ? out_bits : nullptr, dW, db, B, N, Cin, Cout, K, part,
-                                 part_bytes, handled, dry_run, defer)) return rc;
+                                 part_bytes, handled, dry_run, defer, dw_split)) return rc;
     if (*handled) return MVH_OK;
   }
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;

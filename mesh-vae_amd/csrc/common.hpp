@@ -99,6 +99,10 @@ struct DebugCfg {
                            //    deferred reductions emptied the side lane's backlog the lane is the faster place: 570 vs 576 us)
   int fork_batch = 1;      // conv layers sharing one fork event (1..4)
   int l0_lane = 2;         // level-0 weight gradient on the dense lane, behind the level-0 dX, in this many launches (0: conv lane, one launch)
+  int l0_lane_any = 0;     // 1: ... at any batch size >= 16 (default: 32 < B <= 64, where the one launch is one round over the chip)
+  int l0_lane_bf = 1;      // ... with bf16 storage as well
+  int enc_dense = -2;      // encoder stage whose weight gradient runs on the dense lane instead of the conv lane (-1: none,
+                           // -2: the coarsest one when the level-0 lane is in use)
   int l0_hold = 1;         // ... behind this many further forks of the main chain
   int fork_small = 400;    // with fork_batch = 1: layers of at most this many vertices share a fork in pairs (0: never)
   int no_gstack_mfma = 0;  // big-level fallbacks of cheb_conv.hip
@@ -191,7 +195,7 @@ int l0h_pack_dwords(int K);
 // ... and its weight gradient (cheb_dw_l0h.hip)
 int try_cheb_dw_l0h(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const uint8_t* out_bits,
                     float* dW, float* db, int B, int N, int Cin, int Cout, int K, float* part, size_t part_bytes,
-                    bool* handled, bool dry_run, DwReduceEntry* defer);
+                    bool* handled, bool dry_run, DwReduceEntry* defer, int dw_split = 1);
 // levels too big for the slab kernels (5120 .. 20480 vertices): the whole recurrence of a (mesh, channel pair) in one
 // launch (cheb_big.hip): the T_k stack of the forward / dW, and the Clenshaw sum of a stack G [K][B][N][C] (dX).
 // pm: the stack planes are pair-major [B][C/2][N][2] instead of rows [B][N][C] (what the 16 -> 16 producers / consumers

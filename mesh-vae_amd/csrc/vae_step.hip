@@ -511,6 +511,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     float* unpooled;                        // fallback: un-pool with unpool_t into this buffer first
     const float* tx;                        // T_k stack kept by the forward (big levels), else null
     ConvIO io;
+    bool to_dense;                          // run on the dense lane (behind whatever is queued there)
   };
   PendingDw pending[6];
   int n_pending = 0;
@@ -522,8 +523,15 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // therefore held back until the fork BEHIND the level's dX kernel (chip-filling as well: side by side the two would only
   // take turns) and then runs on the dense lane in l0_lane launches of B / l0_lane meshes, one behind the other: at most
   // 256 / l0_lane CUs are taken at a time and the latency-bound small-level chain runs on the others.
-  const int l0_split = (!lane2 && !bf && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits && B >= 16 &&
-                        dbg().l0_lane > 1) ? dbg().l0_lane : 0;
+  // MEASURED (B = 64, fp32): 489-496 against 512 us per step (profiles/r03_ab_l0_lane.txt); bf16 storage 459-468 against 483;
+  // three launches 530, a lane of its own instead of the dense lane 502, behind one more fork 506-511.  It pays when the ONE
+  // launch would be a single round over the whole chip (128 < 4 B <= 256 workgroups): at B = 32 the kernel holds half the
+  // CUs as it is (451 against 433 us with the cut), at B = 128 / 256 it runs several rounds either way (854 / 1547 against
+  // 844 / 1490) -- so the lane is taken for 32 < B <= 64 only (debug switch l0_lane_any lifts the bound, tests).
+  const bool l0_fits = (B > 32 && B <= 64) || (dbg().l0_lane_any && B >= 16);
+  const int l0_split = (!lane2 && (!bf || dbg().l0_lane_bf) && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits &&
+                        l0_fits && dbg().l0_lane > 1) ? dbg().l0_lane : 0;
+  bool next_to_dense = false;   // lane hint for the next conv_dw_side call
   PendingDw held;
   bool have_held = false;
   int held_forks = 0;
@@ -535,7 +543,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (n_pending > 0) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
       if ((also_dense && (dstream != sstream || n_pending == 0)) || (lane2 && n_pending > 0))
         MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
-      if (launch_held && !also_dense) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
+      bool any_dense = launch_held;
+      for (int q = 0; q < n_pending; ++q) any_dense = any_dense || pending[q].to_dense;
+      if (any_dense && !also_dense) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
       ev = (ev + 1) % side->n_ev;
     }
     if (launch_held) { pending[n_pending++] = held; have_held = false; }   // (pending has room: a flush comes at two items at the latest)
@@ -553,6 +563,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
         continue;
       }
       if (is_l0) { sstream = dstream; ss = ss2; w.io.dw_split = l0_split; }
+      else if (w.to_dense) { sstream = dstream; ss = ss2; }
       const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
       const float* dout = w.dout;
       if (w.dout_pool) {
@@ -588,7 +599,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       if (sk == 1 || (sk == 2 && N <= 400) || (sk == 3 && N > 2047) || (sk == 4 && N > 400 && N <= 2047)) return MVH_OK;
     }
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
-                                     dout_pool, unpool_t, unpooled, tx, io};
+                                     dout_pool, unpool_t, unpooled, tx, io,
+                                     next_to_dense && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits};
+    next_to_dense = false;
     // A fork is an event record between two kernels of the critical chain: 3.5 us of that chain.  The weight
     // gradients of the coarse levels (<= fork_small vertices, default 400: two 17 us kernels at 79 / 313 vertices) are short
     // enough to wait for the next layer's fork: two such layers share one.  MEASURED: 515-517 against 521-526 us per step;
@@ -734,6 +747,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       // weight gradient: queued for the side lane (fused un-pooling, explicit un-pooling there if not eligible);
       // debug switch tail_main = 1 puts layer 1's dW on the main stream behind layer 0's instead (round 1's
       // arrangement, when the side lane still had a backlog at this point)
+      // the coarsest encoder stage's weight gradient goes to the dense lane (behind the dense layers' there): with the
+      // level-0 lane the conv lane is the one that finishes last.  MEASURED: 486 against 494 us per step (stage n - 2: 494)
+      next_to_dense = !lane2 && i == (dbg().enc_dense == -2 ? (l0_split ? n - 1 : -1) : dbg().enc_dense);
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]), io,

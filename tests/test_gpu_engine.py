@@ -689,7 +689,7 @@ def test_bench_infer_line_contract():
     assert d["config"]["hipgraph"] is True and d["config"]["replay_equals_eager_bitwise"] is True
 
 
-@pytest.mark.parametrize("B", [5, 16, 40])
+@pytest.mark.parametrize("B", [5, 16, 40, 64])
 def test_round3_forms_against_their_debug_switches(B):
     """Every form this round added to the native step has a debug switch that restores the previous launch sequence; the
     step must not care: storing only what is read (keep_enc_out), the final layer's map inside the loss launch
@@ -714,7 +714,8 @@ def test_round3_forms_against_their_debug_switches(B):
         torch.manual_seed(666)
         net = cheb_VAE(3, dict(CFG_5K), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
         key, val = switch if switch else ("keep_enc_out", 0)
-        with debug_switch(key, val):
+        # (l0_lane_any: the level-0 lane at these batch sizes too -- by default it is taken for 32 < B <= 64 only)
+        with debug_switch("l0_lane_any", 1), debug_switch(key, val):
             nat = NativeStep(net, B)
             drop_u = torch.rand(B * nat.u_cols, generator=torch.Generator().manual_seed(9)).to(dev)
             loss, corr, recon, (kld, rec, z_), yh = nat.forward_backward(x, x.double(), y, eps=eps, drop_u=drop_u)
