@@ -559,7 +559,7 @@ k_latent_wgrad(const float* __restrict__ h, const float* __restrict__ y, const f
   float s = 0.f;
   // Sixteen meshes' operands are fetched before their products are added (clamped rows past the batch, predicated adds):
   // the sums run in the order of the plain loop -- chain t takes the meshes b = t mod 4, ascending -- but the kernel waits
-  // for B / 16 rounds of loads instead of B / 4 (20 -> 8 us at B = 64; it is the last launch of the dense lane)
+  // for B / 16 rounds of loads instead of B / 4 (22.7 -> 11.3 us in the step at B = 64; among the last launches of the dense lane)
   constexpr int kU = 16;
   if (o < C) {
     if (j > H) return;  // classifier input is only [H] (+ bias slot at j == H)
