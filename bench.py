@@ -280,7 +280,12 @@ def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "d
         # duration that includes the kernels running beside it; the kernel's own speed is the isolated figure.
         out["in_step"] = {"launches_per_step": 2, "meshes_per_launch": B // 2,
                           "algorithmic_bytes_per_launch": top["bytes"] // 2,
-                          "note": "half-batch launches beside the main chain; rocprof avg_us is per half-batch launch, contended"}
+                          "pmc_hbm_bytes_per_launch": out["traffic"],
+                          "note": "half-batch launches beside the main chain; rocprof avg_us and the PMC counters of the "
+                                  "committed profile are per half-batch launch (contended); `traffic` above is 2 x the "
+                                  "half-batch counter figure, i.e. per whole batch like `achieved`"}
+        if out["traffic"] is not None:
+            out["traffic"] = 2 * out["traffic"]
     if rocprof_top:
         out["rocprof_top"] = {"file": f"profiles/{tag}_kernel_stats.csv", "by_total_time": rocprof_top}
     if prof:
