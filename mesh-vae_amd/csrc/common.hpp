@@ -99,7 +99,7 @@ struct DebugCfg {
                            //    deferred reductions emptied the side lane's backlog the lane is the faster place: 570 vs 576 us)
   int fork_batch = 1;      // conv layers sharing one fork event (1..4)
   int l0_lane = 2;         // level-0 weight gradient on the dense lane, behind the level-0 dX, in this many launches (0: conv lane, one launch)
-  int l0_lane_any = 0;     // 1: ... at any batch size >= 16 (default: 32 < B <= 64, where the one launch is one round over the chip)
+  int l0_lane_any = 0;     // 1: ... at any batch size >= 16 (default: 56 < B <= 64, where the one launch holds nearly every CU)
   int l0_lane_bf = 1;      // ... with bf16 storage as well
   int enc_dense = -2;      // encoder stage whose weight gradient runs on the dense lane instead of the conv lane (-1: none,
                            // -2: the coarsest one when the level-0 lane is in use)

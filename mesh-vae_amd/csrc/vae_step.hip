@@ -525,10 +525,12 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // 256 / l0_lane CUs are taken at a time and the latency-bound small-level chain runs on the others.
   // MEASURED (B = 64, fp32): 489-496 against 512 us per step (profiles/r03_ab_l0_lane.txt); bf16 storage 459-468 against 483;
   // three launches 530, a lane of its own instead of the dense lane 502, behind one more fork 506-511.  It pays when the ONE
-  // launch would be a single round over the whole chip (128 < 4 B <= 256 workgroups): at B = 32 the kernel holds half the
-  // CUs as it is (451 against 433 us with the cut), at B = 128 / 256 it runs several rounds either way (854 / 1547 against
-  // 844 / 1490) -- so the lane is taken for 32 < B <= 64 only (debug switch l0_lane_any lifts the bound, tests).
-  const bool l0_fits = (B > 32 && B <= 64) || (dbg().l0_lane_any && B >= 16);
+  // launch would hold (nearly) EVERY CU in one round: at B = 32 the kernel takes half the CUs as it is (451 against 433 us
+  // with the cut), at B = 33 / 40 / 48 the single launch leaves 124 / 96 / 64 CUs to the chain and is the better form (441 /
+  // 452 / 473 against 461 / 462 / 486), at B = 56 it is a draw (495), at B = 128 / 256 the kernel runs several rounds either
+  // way (854 / 1547 against 844 / 1490) -- so the lane is taken for 56 < B <= 64 only (debug switch l0_lane_any lifts the
+  // bound, tests).
+  const bool l0_fits = (B > 56 && B <= 64) || (dbg().l0_lane_any && B >= 16);
   const int l0_split = (!lane2 && (!bf || dbg().l0_lane_bf) && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits &&
                         l0_fits && dbg().l0_lane > 1) ? dbg().l0_lane : 0;
   bool next_to_dense = false;   // lane hint for the next conv_dw_side call

@@ -714,7 +714,7 @@ def test_round3_forms_against_their_debug_switches(B):
         torch.manual_seed(666)
         net = cheb_VAE(3, dict(CFG_5K), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
         key, val = switch if switch else ("keep_enc_out", 0)
-        # (l0_lane_any: the level-0 lane at these batch sizes too -- by default it is taken for 32 < B <= 64 only)
+        # (l0_lane_any: the level-0 lane at these batch sizes too -- by default it is taken for 56 < B <= 64 only)
         with debug_switch("l0_lane_any", 1), debug_switch(key, val):
             nat = NativeStep(net, B)
             drop_u = torch.rand(B * nat.u_cols, generator=torch.Generator().manual_seed(9)).to(dev)
