@@ -24,7 +24,8 @@ struct StepPlan {
   // activations (floats): conv outputs / pooled, decoder unpooled / conv outputs
   std::vector<size_t> encA, encP, decU, decC, g_encA, g_encP, g_decU, g_decC;
   size_t h, zy, d1, d2, g_h, g_zy, g_d1, g_d2, g_recon, d_mu, d_lv, d_yhat, d_heads;
-  size_t scratch_main, scratch_side, scratch_side2, scratch_bytes;   // (scratch_side2: second gradient lane, kNoBits at streaming levels)
+  size_t scratch_main, scratch_side, scratch_side2, scratch_bytes;   // (scratch_side2: the dense lane's conv weight gradients,
+  size_t scratch2_bytes;                                               //  levels of the LDS-resident kernels only: scratch2_bytes)
   std::vector<size_t> pk_enc_f, pk_enc_b, pk_dec_f, pk_dec_b;  // slab-packed conv weights (fwd / W^T)
   std::vector<size_t> dwPartEnc, dwPartDec;  // per-layer dW partial tiles (reduced together after the join)
   std::vector<size_t> dwPartBytesEnc, dwPartBytesDec;
@@ -55,19 +56,22 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   auto A = [&](std::vector<size_t>& v, int i, size_t floats) { v[i] = take(cur, floats); };
   p.encA.resize(n); p.encP.resize(n); p.decU.resize(n); p.decC.resize(n);
   p.g_encA.resize(n); p.g_encP.resize(n); p.g_decU.resize(n); p.g_decC.resize(n);
-  size_t scratch = 0;
+  size_t scratch = 0, scratch2 = 256;   // scratch2: backward calls of the levels of <= 5119 vertices (the dense lane takes only those)
   auto upd = [&](size_t b) { if (b > scratch) scratch = b; };
+  auto upd2 = [&](size_t b, int N) { if (N + 1 <= 5120 && b > scratch2) scratch2 = b; };
   for (int i = 0; i < n; ++i) {
     const size_t a = (size_t)B * p.Nn[i] * p.f[i + 1], q = (size_t)B * p.Nn[i + 1] * p.f[i + 1];
     A(p.encA, i, a); A(p.g_encA, i, a); A(p.encP, i, q); A(p.g_encP, i, q);
     upd(mvh_cheb_conv_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]));
     upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]));
+    upd2(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[i], p.f[i], p.f[i + 1], d->K[i]), p.Nn[i]);
     // decoder stage i works at level n-i-1: filters[-i-1] -> filters[-i-2]
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const size_t u = (size_t)B * p.Nn[lvl] * cin, c = (size_t)B * p.Nn[lvl] * cout;
     A(p.decU, i, u); A(p.g_decU, i, u); A(p.decC, i, c); A(p.g_decC, i, c);
     upd(mvh_cheb_conv_ws_bytes(B, p.Nn[lvl], cin, cout, d->K[i]));
     upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[lvl], cin, cout, d->K[i]));
+    upd2(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[lvl], cin, cout, d->K[i]), p.Nn[lvl]);
   }
   upd(mvh_cheb_conv_ws_bytes(B, p.Nn[0], p.f[1], p.f[0], d->K[n]));
   upd(mvh_cheb_conv_bwd_ws_bytes(B, p.Nn[0], p.f[1], p.f[0], d->K[n]));
@@ -124,8 +128,8 @@ static int build_plan(const mvh_vae_desc_t* d, int B, StepPlan& p) {
   p.scratch_bytes = align_up(scratch, 256);
   p.scratch_main = cur; cur += p.scratch_bytes;
   p.scratch_side = cur; cur += p.scratch_bytes;
-  p.scratch_side2 = kNoBits;
-  if (p.Nn[0] + 1 <= 5120) { p.scratch_side2 = cur; cur += p.scratch_bytes; }   // (the streaming levels' scratch is GBs: no second lane there)
+  p.scratch2_bytes = align_up(scratch2, 256);
+  p.scratch_side2 = cur; cur += p.scratch2_bytes;
   p.total = cur + 256;
   return MVH_OK;
 }
@@ -556,7 +560,6 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       bool deferred = false, fused = false;
       hipStream_t sstream = sstream_conv;      // (shadows: this item's lane)
       void* ss = ss_conv;
-      if (lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1)) { sstream = dstream; ss = ss2; }
       const bool is_l0 = l0_split && w.N + 1 > 2048 && w.N + 1 <= 5120 && w.cin == 16 && w.cout == 16 && !w.dout_pool;
       if (is_l0 && !(launch_held && q == n_pending - 1)) {   // not yet: behind the next fork
         held = w;
@@ -564,13 +567,15 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
         held_forks = dbg().l0_hold < 1 ? 1 : dbg().l0_hold;
         continue;
       }
-      if (is_l0) { sstream = dstream; ss = ss2; w.io.dw_split = l0_split; }
-      else if (w.to_dense) { sstream = dstream; ss = ss2; }
+      size_t ss_bytes = p.scratch_bytes;
+      if (lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1)) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; }
+      if (is_l0) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; w.io.dw_split = l0_split; }
+      else if (w.to_dense && w.N + 1 <= 5120) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; }
       const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
       const float* dout = w.dout;
       if (w.dout_pool) {
         TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, w.tx, nullptr, w.dW, w.db, B, w.N,
-                               w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, w.dout_pool, &fused, w.bits,
+                               w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, w.dout_pool, &fused, w.bits,
                                nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
                                &deferred, nullptr, nullptr, w.io));
         MVH_REQUIRE(fused || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the weight-gradient kernel");
@@ -581,7 +586,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       }
       if (!fused)
         TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, w.tx, nullptr, w.dW, w.db, B, w.N,
-                               w.cin, w.cout, w.K, w.act, ss, p.scratch_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
+                               w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
                                can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred,
                                nullptr, nullptr, w.io));
       if (deferred) ++red.n;
@@ -752,6 +757,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       // the coarsest encoder stage's weight gradient goes to the dense lane (behind the dense layers' there): with the
       // level-0 lane the conv lane is the one that finishes last.  MEASURED: 486 against 494 us per step (stage n - 2: 494)
       next_to_dense = !lane2 && i == (dbg().enc_dense == -2 ? (l0_split ? n - 1 : -1) : dbg().enc_dense);
+      // (configs[3], MEASURED and not kept: the 5 041-vertex encoder stage's chip-filling weight gradient on the dense lane instead
+      //  of the end of the conv lane's queue, in one or two launches: 2338-2348 against 2308-2311 us -- it then takes the CUs of
+      //  that level's dX kernel on the main chain)
       if (!(i == 1 && tail_on_main))
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]), io,
