@@ -377,15 +377,34 @@ def capture_inference(fn, x, dev):
     return g, out
 
 
-def infer_latencies(dev, steps, warmup):
+def estimate_diff_batched_fn(net):
+    """The same inference with the two decodes (own label, opposite label) as ONE 2B-mesh decoder pass -- what the
+    package's own crecon_ops.estimate_diff_device does; the decoder is per-mesh, so the results are bitwise the two
+    calls' (asserted by the caller)."""
+    def run(x):
+        h = net.encoder(x)
+        y_hat = net.classifier(h)
+        y = torch.nn.functional.one_hot(y_hat.argmax(-1), 2).to(torch.float32)
+        mu = net.z_mean(torch.cat([y, h], -1))
+        both = net.sample(torch.cat([y, 1.0 - y]), torch.cat([mu, mu]))
+        return both[:x.shape[0]], both[x.shape[0]:], y_hat
+    return run
+
+
+def infer_latencies(dev, steps, warmup, batched=False):
     """(hipGraph replay, eager) latency in ms of encode + classify + 2 x decode at B = 1 / 32 / 256; the replay is checked
-    bitwise against the eager result."""
+    bitwise against the eager result.  batched: the two decodes as one 2B-mesh pass (checked bitwise against the two
+    calls)."""
     net = build_model(dev).eval()
-    fn = estimate_diff_fn(net)
+    fn = estimate_diff_batched_fn(net) if batched else estimate_diff_fn(net)
     lat, eager = {}, {}
     iters = max(steps, 20)
     for B in (1, 32, 256):
         x = torch.randn(B, 4998, 3, device=dev)
+        if batched:
+            with torch.no_grad():
+                for a, b in zip(fn(x), estimate_diff_fn(net)(x)):
+                    assert torch.equal(a, b), "batched decode differs from the two decoder calls"
         with torch.no_grad():
             for _ in range(max(warmup, 3)):
                 ref = fn(x)
@@ -421,6 +440,12 @@ def run_infer(args, dev, emit):
                                            "replay_equals_eager_bitwise": True},
            "latency_ms": {f"b{b}": lat[b] for b in lat}, "eager_latency_ms": {f"b{b}": eager[b] for b in eager},
            "meshes_per_s": {f"b{b}": b / lat[b] * 1e3 for b in lat}}
+    # the package's own op for the same inference (crecon_ops.estimate_diff_device: both decodes in one 2B-mesh pass);
+    # never `value` -- the headline stays the reference script's call sequence (two net.sample calls)
+    _, lat2, eager2, _ = infer_latencies(dev, args.steps, args.warmup, batched=True)
+    out["batched_decode"] = {"latency_ms": {f"b{b}": lat2[b] for b in lat2}, "eager_latency_ms": {f"b{b}": eager2[b] for b in eager2},
+                             "equals_two_calls_bitwise": True,
+                             "note": "own label and opposite label decoded in one 2B-mesh pass (crecon_ops.estimate_diff_device)"}
     # one inference = 1 encoder + 2 decoder passes: ~1.5 x the forward's module-boundary bytes
     bytes_per_mesh = 1.5 * ALGO_BYTES_FWD_PER_MESH
     ach = 256 / lat[256] * 1e3 * bytes_per_mesh / 1e9
@@ -604,10 +629,13 @@ def main():
                                           args.seed)}
             # ... and configs[4] (inference, hipGraph replay): the latencies of `--config infer`
             _, lat, eager, it = infer_latencies(dev, max(20, args.steps), max(3, args.warmup // 2))
+            _, lat2, _, _ = infer_latencies(dev, max(20, args.steps), max(3, args.warmup // 2), batched=True)
             out["variants"]["infer"] = {"workload": WORKLOADS["infer"], "unit": "ms", "steps": it,
                                         "latency_ms": {f"b{b}": lat[b] for b in lat},
                                         "eager_latency_ms": {f"b{b}": eager[b] for b in eager},
-                                        "replay_equals_eager_bitwise": True}
+                                        "replay_equals_eager_bitwise": True,
+                                        # (both decodes in one 2B-mesh pass, crecon_ops.estimate_diff_device: bitwise the two calls)
+                                        "batched_decode_latency_ms": {f"b{b}": lat2[b] for b in lat2}}
         emit(out)
     if dist.is_initialized():
         dist.barrier()
