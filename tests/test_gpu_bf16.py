@@ -340,3 +340,30 @@ def test_bf16_step_matrix_pipe_kernels_against_the_unpack_form():
           f"loss {res['mfma'][2]:.3f} / {res['unpack'][2]:.3f}")
     assert not torch.equal(ra, rb)                       # two different kernel families really ran
     assert e_recon < 8e-3 and worst < 2e-2, (e_recon, worst, worst_k)
+
+
+@pytest.mark.parametrize("B", [24, 64])
+def test_bf16_level0_lane_moves_launches_only(B):
+    """The level-0 lane with bf16 storage (k_cheb_dw_l0h in part-batch launches on the dense lane, `DwL0hDims::mesh0`;
+    taken by default for 56 < B <= 64, here also at B = 24 through l0_lane_any): every output and every gradient bitwise
+    the single launch's (l0_lane = 0) and a three-way cut's."""
+    from meshvae_hip import debug_switch
+    from meshvae_hip.engine import NativeStep
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 4998, 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+    res = {}
+    for lanes in (0, 2, 3):
+        net = _model("5k", dev, dropout=0.2).train()
+        with debug_switch("l0_lane_any", 1), debug_switch("l0_lane", lanes):
+            nat = NativeStep(net, B, storage="bf16")
+            drop_u = torch.rand(B * nat.u_cols, generator=torch.Generator().manual_seed(9)).to(dev)
+            loss, _, recon, _, _ = nat.forward_backward(x, x, y, eps=eps, drop_u=drop_u)
+            torch.cuda.synchronize()
+        res[lanes] = (loss.clone(), recon.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    for lanes in (2, 3):
+        assert torch.equal(res[lanes][0], res[0][0]) and torch.equal(res[lanes][1], res[0][1])
+        for k, gref in res[0][2].items():
+            assert torch.equal(res[lanes][2][k], gref), (lanes, k)
