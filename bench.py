@@ -250,48 +250,80 @@ def conv_ops(net, B, dev, dtype="f32"):
     return ops
 
 
+def time_kernel_median(fn, repeats=5, iters=30, warm=5):
+    """Median of `repeats` HIP-event averages (time_kernel): one slow repeat -- another process's burst on the box, a
+    clock dip -- must not decide which launch the bench calls dominant (BENCH_r03: `conv fwd dec0` once 43 us for 10)."""
+    ts = sorted(time_kernel(fn, iters, warm if r == 0 else 1) for r in range(repeats))
+    return ts[len(ts) // 2]
+
+
+def step_launches(kernel, B, config, dtype):
+    """How many launches of `kernel` ONE train step issues (engine rule, csrc/vae_step.hip `l0_split`): the 5k level's
+    weight-gradient kernel runs as `l0_lane` part-batch launches on the dense lane for 56 < B <= 64 (bf16 storage: only with
+    the l0_lane_bf switch), every other conv kernel once."""
+    from meshvae_hip import lib
+    L = lib()
+    if config != "train5k" or not (kernel or "").startswith(("k_cheb_dw_lds<16,10,512,4>", "k_cheb_dw_l0h")):
+        return 1
+    lane = L.mvh_debug_get(b"l0_lane")
+    fits = (56 < B <= 64) or (L.mvh_debug_get(b"l0_lane_any") and B >= 16)
+    if lane > 1 and fits and (dtype == "f32" or L.mvh_debug_get(b"l0_lane_bf")):
+        return int(lane)
+    return 1
+
+
 def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "dX", "dW")):
-    """The `roofline` object of the bench line: the conv launch that costs the step most, by the rocprofv3 total-time
-    ranking of the committed profile taken on these sources when there is one (profiles/<tag>_kernel_stats.csv),
-    otherwise by the live isolated timings; `achieved` always comes from the live HIP-event average."""
+    """The `roofline` object of the bench line, for the conv launch that costs most.
+
+    Two figures, both reproducible from what the line and profiles/ carry:
+      * `frac` (isolated): algorithmic bytes of the whole-batch launch / its live HIP-event time (median of 5 repeats of a
+        30-launch average, on the launching stream) / peak.  This is the kernel's own speed.
+      * `in_step.frac`: algorithmic bytes of ONE launch as the train step issues it / the rocprofv3 `avg_us` of that kernel
+        in the committed profile taken on these sources (profiles/<tag>_kernel_stats.csv) / peak -- lower, because in the
+        step the launch shares the chip with the other two streams; `in_step.traffic_ratio` = PMC HBM bytes per launch
+        (profiles/<tag>_pmc.json, hbm_bytes) / algorithmic bytes per launch.  None when no committed profile matches the
+        source hash of the kernels being benchmarked."""
     ops = [o for o in conv_ops(net, B, dev, dtype) if o["op"].split()[1] in kinds]
     for o in ops:
-        o["ms"] = time_kernel(o["fn"])
+        o["ms"] = time_kernel_median(o["fn"])
     tag, pmc, stats = matching_profile(config, dtype)
     # Ranking: every conv launch of the model by its ISOLATED HIP-event time (all 25, not a hand-picked few).  The
     # rocprofv3 totals of the committed profile are listed beside it (rocprof_top): under the step's three concurrent
     # streams a small kernel's rocprof duration includes the time its workgroups wait for CUs that a chip-filling
-    # level-0 kernel of another stream holds (e.g. k_cheb_lds<16,1,0,4,true>: avg 30 us, min 7.5 us in r02_b), so
-    # the rocprof total ranks waiting, not work; both views are printed so a reader can check either.
-    ranking = "isolated HIP-event time of every conv launch (x 1 launch per step each)"
+    # level-0 kernel of another stream holds, so the rocprof total ranks waiting, not work; both views are printed.
+    ranking = "isolated HIP-event time of every conv launch, median of 5 x 30-launch averages (x 1 launch per step each)"
     top = max(ops, key=lambda o: o["ms"])
     rocprof_top = [{"kernel": k, "calls": v[0], "total_us": v[1], "avg_us": v[2]}
                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:5]]
     ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
     prof = pmc.get(top["kernel"] or "", {})
+    n_launch = step_launches(top["kernel"], B, config, dtype)
+    pmc_bytes = prof.get("hbm_bytes")                      # per launch AS PROFILED (i.e. per part-batch launch in the step)
     out = {"bound": "hbm", "kernel": f'{top["kernel"] or "split/stack path"}: {top["op"]}', "achieved": ach,
-           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": prof.get("hbm_bytes"),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": None if pmc_bytes is None else n_launch * pmc_bytes,   # per whole-batch launch, like `achieved`
            "avg_launch_us": top["ms"] * 1e3, "algorithmic_bytes_per_launch": top["bytes"], "ranking": ranking}
-    if (top["kernel"] or "").startswith(("k_cheb_dw_lds<16,10,512,4>", "k_cheb_dw_l0h")) and 32 < B <= 64 and config == "train5k":
-        # the figure above is the kernel on the whole batch in ONE launch (what the module-level op issues).  The train
-        # step issues it as two half-batch launches on the dense lane (the "level-0 lane", DESIGN 0.1): the kernel is one
-        # 160 KB workgroup per CU, and on half the CUs at a time it no longer stops the small-level chain of the main
-        # stream.  rocprofv3 therefore lists 2 calls per step, each over B / 2 meshes (half the algorithmic bytes), with a
-        # duration that includes the kernels running beside it; the kernel's own speed is the isolated figure.
-        out["in_step"] = {"launches_per_step": 2, "meshes_per_launch": B // 2,
-                          "algorithmic_bytes_per_launch": top["bytes"] // 2,
-                          "pmc_hbm_bytes_per_launch": out["traffic"],
-                          "note": "half-batch launches beside the main chain; rocprof avg_us and the PMC counters of the "
-                                  "committed profile are per half-batch launch (contended); `traffic` above is 2 x the "
-                                  "half-batch counter figure, i.e. per whole batch like `achieved`"}
-        if out["traffic"] is not None:
-            out["traffic"] = 2 * out["traffic"]
+    st = stats.get(top["kernel"] or "")
+    in_bytes = top["bytes"] // n_launch
+    in_step = {"launches_per_step": n_launch, "meshes_per_launch": B // n_launch, "algorithmic_bytes_per_launch": in_bytes,
+               "avg_us": st[2] if st else None, "achieved": None, "frac": None,
+               "pmc_hbm_bytes_per_launch": pmc_bytes, "traffic_ratio": None if not pmc_bytes else pmc_bytes / in_bytes,
+               "kernel_stats": f"profiles/{tag}_kernel_stats.csv" if tag else None,
+               "pmc": f"profiles/{tag}_pmc.json" if tag else None,
+               "note": "the launch as the train step issues it, beside the other two streams: algorithmic_bytes_per_launch / "
+                       "avg_us (rocprofv3 --kernel-trace --stats of the committed profile taken on these sources) / peak; "
+                       "traffic_ratio = hbm_bytes of the PMC passes ((2 FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction of "
+                       "MI355X_MICROARCH.md) / algorithmic bytes.  None: no committed profile matches these kernel sources"}
+    if st and st[2] > 0:
+        in_step["achieved"] = in_bytes / (st[2] * 1e-6) / 1e9
+        in_step["frac"] = in_step["achieved"] / HBM_PEAK_GBS
+    out["in_step"] = in_step
     if rocprof_top:
         out["rocprof_top"] = {"file": f"profiles/{tag}_kernel_stats.csv", "by_total_time": rocprof_top}
     if prof:
         out["profile"] = {"tag": tag, "mfma_util": prof.get("mfma_util"), "lds_conflict_frac": prof.get("lds_conflict_frac"),
                           "scratch_bytes_per_lane": prof.get("scratch_bytes_per_lane"),
-                          "rocprof_avg_us": stats.get(top["kernel"], (0, 0, None))[2]}
+                          "rocprof_avg_us": st[2] if st else None}
     table = {o["op"]: {"kernel": o["kernel"], "avg_us": round(o["ms"] * 1e3, 2),
                        "algo_GBps": round(o["bytes"] / (o["ms"] * 1e-3) / 1e9, 1)} for o in ops}
     return out, table
@@ -535,8 +567,13 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # RCCL ("nccl") is the product backend.  MESHVAE_DIST_BACKEND=gloo is the REHEARSAL of this multi-rank branch on a
+        # one-GPU box (tests/test_gpu_ddp.py: two ranks share cuda:0; RCCL refuses two ranks on one device)
+        backend = os.environ.get("MESHVAE_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)

@@ -1346,6 +1346,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     if (defer && dw_done) *deferred = true;
   }
   MVH_REQUIRE(!io.src3_g || dw_done, "cheb_conv_bwd: lazy output-gradient rows (src3) need the LDS-resident dW kernel");
+  // strided x: the dry run above asked without the mask operands; if the real call declined after all (e.g. a mask
+  // pointer off its 16-byte alignment) nothing below can read x through its row map -- the caller makes the copy
+  if (io.x_map && dW && !dw_done)
+    return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: the LDS-resident dW kernel declined a strided x (N=%d %d->%d K=%d)",
+                N, Cin, Cout, K);
   if (!dw_done && bf)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_bwd: bf16 storage exists on the LDS-resident dW kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);

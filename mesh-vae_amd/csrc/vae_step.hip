@@ -194,7 +194,9 @@ static SideStream* side_for_device() {
     if (hipStreamCreateWithPriority(&s.dense, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
+    // dense_done is the one event whose data can leave the device (mvh_vae_wait_dense_grads hands the dense gradients to an
+    // RCCL stream that peer GPUs read): it keeps the default system-scope fence
+    if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.tstack_done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
     s.n_ev = 64;
   }
@@ -541,9 +543,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   PendingDw held;
   bool have_held = false;
   int held_forks = 0;
-  auto flush_dw = [&](bool also_dense) -> int {  // one event for everything queued (+ the dense lane)
+  auto flush_dw = [&](bool also_dense, bool force_held = false) -> int {  // one event for everything queued (+ the dense lane)
     if (n_pending == 0 && !also_dense && !have_held) return MVH_OK;
-    const bool launch_held = have_held && (also_dense || n_pending == 0 || --held_forks <= 0);
+    const bool launch_held = have_held && (also_dense || force_held || n_pending == 0 || --held_forks <= 0);
     if (sstream != main) {
       MVH_HIP(hipEventRecord(side->ev[ev], main));
       if (n_pending > 0) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
@@ -760,7 +762,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       // (configs[3], MEASURED and not kept: the 5 041-vertex encoder stage's chip-filling weight gradient on the dense lane instead
       //  of the end of the conv lane's queue, in one or two launches: 2338-2348 against 2308-2311 us -- it then takes the CUs of
       //  that level's dX kernel on the main chain)
-      if (!(i == 1 && tail_on_main))
+      if (i == 1 && tail_on_main) next_to_dense = false;   // (no call below to consume the hint: it must not leak to a later layer)
+      else
       TRY(conv_dw_side(&d->lap[i], &d->lap_t[i], xin, P[ix.encW(i)], F(p.encA[i]), F(p.g_encP[i]), G[ix.encW(i)],
                        G[ix.encB(i)], p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, BITS(p.encBits[i]), io,
                        p.dwPartEnc[i], p.dwPartBytesEnc[i], &d->down[i], &d->down_t[i], F(p.g_encA[i]),
@@ -827,7 +830,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     }
     if (deferred) ++red.n;
   }
-  TRY(flush_dw(false));
+  TRY(flush_dw(false, true));   // the last fork also takes a level-0 item still held back (debug switch l0_hold >= 2)
+  MVH_REQUIRE(!have_held && n_pending == 0, "vae_backward: a weight-gradient launch was still queued at the join");
   // join
   if (dstream != main && dstream != sstream) {
     MVH_HIP(hipEventRecord(side->ev[ev], dstream));

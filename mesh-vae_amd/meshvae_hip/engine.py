@@ -166,7 +166,6 @@ class _Batch:
 
 
 class TrainStep:
-    U_AHEAD = 16     # eager: steps' worth of dropout uniforms drawn by one generator launch
     """One data-parallel train step: forward + backward (+ all-reduce) + Adam.
 
     Eager (`use_graph=False`, the default) is the fast path on ROCm 7.2: the C++ launch sequence keeps the host ahead
@@ -178,6 +177,8 @@ class TrainStep:
     (cheb_VAE.py:316), and the dropout uniforms on the device generator (a generator consumed inside a capture would
     either raise or bake one offset -- one mask -- into every replay).
     """
+
+    U_AHEAD = 16     # eager: steps' worth of dropout uniforms drawn by one generator launch
 
     def __init__(self, net, batch, lr=1e-3, weight_decay=5e-4, use_graph=False, m_type="train", group=None,
                  native=True, n_micro=1, noise_seed=None, rehearse_allreduce=False, overlap_allreduce=False,
@@ -220,7 +221,10 @@ class TrainStep:
         self._comm = None      # stream of the overlapped dense-gradient all-reduce (created on first use)
         # static buffer (graph-safe), only for the batch size it was built for: any other call of the module
         # (a different B through net(...)) draws fresh host noise as the reference does
-        net._eps_provider = lambda B, Z, device: self.eps if (B == self.B and Z == self.eps.shape[1]) else None
+        # ... and only while this step keeps that buffer filled: with the draw-ahead of _draw_eps a step's noise is a view
+        # of a device block and `self.eps` is never written, so a module-level train-mode call draws its own host noise
+        net._eps_provider = lambda B, Z, device: (self.eps if (B == self.B and Z == self.eps.shape[1] and
+                                                               not self._eps_ahead()) else None)
         net._prepare()                                         # topology upload must precede any capture
         # native=True: the whole forward+backward is one C++ launch sequence (mvh_vae_forward/backward);
         # native=False: the per-module autograd path (what main.py drives through model.forward).

@@ -110,3 +110,34 @@ def test_trainstep_world2_with_dropout_keeps_replicas_identical(tmp_path):
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(WORLD))
     assert torch.equal(r0["param"], r1["param"]) and torch.isfinite(r0["param"]).all()
     assert all(l == l for l in r0["losses"] + r1["losses"])
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    environment), rehearsed on the one GPU of this box: two fresh child processes share cuda:0 and the process group is gloo
+    (MESHVAE_DIST_BACKEND) because RCCL wants one device per rank.  Executes the multi-rank branch of bench.py end to end at
+    the BENCHMARKED size -- the 5k model at 64 meshes per rank (BASELINE configs[2] per-rank shape): init, rank-0 broadcast,
+    one all-reduce per step, barrier + MAX over ranks of the timed region, ONE JSON line from rank 0 only.  No scaling
+    figure is expected from two ranks on one device."""
+    import json
+    import subprocess
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MESHVAE_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64",
+                                       "--steps", "3", "--warmup", "1", "--prewarm-steps", "0", "--no-cpu-baseline",
+                                       "--no-kernel-roofline"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines0) == 1 and not outs[1][0].strip(), (outs[0][0][:300], outs[1][0][:300])   # rank 0 speaks, rank 1 does not
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["per_gpu_batch"] == 64
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 1e6
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "variants" not in d and "cpu_baseline" not in d           # single-GPU legs stay out of a multi-rank line

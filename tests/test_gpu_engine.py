@@ -653,6 +653,21 @@ def _bench_line(*extra):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
+    assert "median" in r["ranking"]
+    # the launch as the step issues it: reproducible from the committed profile files the object names
+    i = r["in_step"]
+    for k in ("launches_per_step", "meshes_per_launch", "algorithmic_bytes_per_launch", "avg_us", "achieved", "frac",
+              "pmc_hbm_bytes_per_launch", "traffic_ratio", "kernel_stats", "pmc"):
+        assert k in i, k
+    assert i["launches_per_step"] * i["algorithmic_bytes_per_launch"] <= r["algorithmic_bytes_per_launch"]
+    if i["avg_us"] is not None:          # a committed profile matches the kernel sources
+        assert abs(i["frac"] - i["algorithmic_bytes_per_launch"] / (i["avg_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-9
+        assert os.path.exists(os.path.join(ROOT, i["kernel_stats"])) and os.path.exists(os.path.join(ROOT, i["pmc"]))
+        if i["pmc_hbm_bytes_per_launch"]:
+            assert abs(i["traffic_ratio"] - i["pmc_hbm_bytes_per_launch"] / i["algorithmic_bytes_per_launch"]) < 1e-9
+            assert r["traffic"] == i["launches_per_step"] * i["pmc_hbm_bytes_per_launch"]
+    else:
+        assert i["frac"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "meshes/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     return d
