@@ -36,6 +36,8 @@ for _p in (ROOT, os.path.join(ROOT, "mesh-vae_amd")):
 # gradient lanes end up sharing the main chain's queue: measured 0.83 ms/step instead of 0.63 with a 1-rank
 # RCCL group (tools/dist_overhead.sh, dist_overhead2.sh).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# stream value waits of the asynchronous launcher on the command processor, not as a spinning shader (meshvae_hip/__init__.py)
+os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -521,6 +523,55 @@ def timed_variant(dev, config, dtype, B, steps, warmup, prewarm, seed):
                               "frac": mps * bpm / 1e9 / HBM_PEAK_GBS, "note": f"meshes/s x {bpm / 1e6:.2f} MB/mesh (SURVEY 8(d))"}}
 
 
+class RefBatch:
+    """What cheb_VAE.forward reads of a torch_geometric Batch (cheb_VAE.py:195-200): .x [B*N, 3], .num_graphs, .edge_index."""
+
+    def __init__(self, x):
+        self.x, self.num_graphs, self.edge_index = x.reshape(-1, x.shape[-1]), x.shape[0], None
+
+
+def reference_loop_variant(dev, B, steps, warmup, prewarm):
+    """The reference's OWN call sequence around the drop-in modules, timed with the headline's protocol -- what an unchanged
+    main.py gets (main.py:74-81 and :251): optimizer.zero_grad() -> model(data, x_gt, sex_hot, m_type="train") ->
+    loss.backward() -> torch.optim.Adam(net.parameters(), lr, weight_decay=5e-4).step(); fp64 x_gt and int64 one-hot labels
+    as main.py:69-71 hand them over; no engine.TrainStep, no fused optimizer."""
+    net = build_model(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+    x = torch.randn(B, net.num_nodes[0], 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    x_gt = x.double()
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    data = RefBatch(x)
+
+    def step():
+        opt.zero_grad()
+        loss, correct, out, z, y_hat = net(data, x_gt, y, m_type="train")
+        loss.backward()
+        opt.step()
+        return loss
+    for i in range(prewarm + warmup):
+        step()
+        if i % 50 == 49:
+            torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    loss = float(loss.detach())
+    assert np.isfinite(loss), "non-finite loss in the reference-loop variant"
+    import meshvae_hip
+    mps = B * steps / dt
+    bpm = ALGO_BYTES_PER_MESH[("train5k", "f32")]
+    return {"workload": WORKLOADS["train5k"] + f", {B} meshes/GPU, f32 -- driven by the reference's loop (main.py:74-81,251): "
+                        "net(data, x_gt, y, m_type='train') -> loss.backward() -> torch.optim.Adam.step() -> zero_grad()",
+            "value": mps, "unit": "meshes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "prewarm_steps": prewarm, "dtype": "f32", "final_loss": loss, "optimizer": "torch.optim.Adam (torch default: foreach)",
+            "async_launcher": meshvae_hip.launcher(dev.index) is not None,
+            "step_roofline": {"bound": "hbm", "achieved": mps * bpm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": mps * bpm / 1e9 / HBM_PEAK_GBS, "note": f"meshes/s x {bpm / 1e6:.2f} MB/mesh (SURVEY 8(d))"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -547,7 +598,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra driver-timed legs of the default line (bf16 storage; the 20k configuration)")
+                    help="skip the extra driver-timed legs of the default line (the reference's own loop; bf16 storage; the "
+                         "20k configuration; inference latencies)")
+    ap.add_argument("--only-reference-loop", action="store_true",
+                    help="time ONLY the reference-API loop variant and print its object (A/B tooling, tools/ab_ref.sh)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (rank 0's JSON): libraries that print there (RCCL writes a five-line version
@@ -582,6 +636,10 @@ def main():
         assert world == 1, "--config infer is a single-GPU latency measurement"
         assert args.dtype == "f32", "--config infer runs the fp32 module path"
         return run_infer(args, dev, emit)
+
+    if args.only_reference_loop:
+        assert world == 1
+        return emit(reference_loop_variant(dev, args.batch, args.steps, args.warmup, max(args.prewarm_steps, 0)))
 
     from meshvae_hip.engine import TrainStep
     net = build_model(dev, args.config)
@@ -661,6 +719,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             out["variants"] = {
+                "reference_loop": reference_loop_variant(dev, B, args.steps, args.warmup, min(prewarm, 100)),
                 "bf16": timed_variant(dev, "train5k", "bf16", B, args.steps, args.warmup, min(prewarm, 100), args.seed),
                 "hires20k": timed_variant(dev, "hires20k", "f32", B, max(10, args.steps // 2), max(3, args.warmup // 2), 20,
                                           args.seed)}

@@ -88,7 +88,7 @@ typedef struct mvh_csr {
  * any other call (the Python binding does, meshvae_hip/__init__.py).  History: 100 = round 1; 300 = `storage`
  * inserted into mvh_vae_desc_t, skip_lo / skip_hi appended to mvh_adam_step / mvh_adam_step_counted (round 2,
  * shipped unversioned), version check introduced (round 3). */
-#define MVH_ABI_VERSION 300
+#define MVH_ABI_VERSION 310
 int mvh_version(void);
 const char* mvh_last_error(void);
 /* Device properties of the current HIP device (arch string e.g. "gfx950"). */
@@ -391,13 +391,47 @@ int mvh_vae_decode(mvh_stream_t stream, const mvh_vae_desc_t* desc, const float*
                    const float* drop_u, int32_t B, float* recon, void* ws, size_t ws_bytes);
 
 /* Data-parallel overlap: make `stream` wait until the DENSE-layer weight gradients written by the
- * most recent mvh_vae_backward issued from this host thread on the current device are final -- classifier_layer,
+ * most recent mvh_vae_backward on the current device (from any host thread: the gradient lanes are per device) are final -- classifier_layer,
  * z_mean, z_log_var, enc_lin, dec_lin, dec_lin_1, dec_lin_2: 98 % of the parameter bytes at default.cfg, and they
  * are complete before the encoder half of the backward starts.  A caller that keeps those parameters contiguous
  * can all-reduce them on `stream` underneath the rest of the backward and only the convolution weights
  * (80 KB) after it.  The reference has no distributed code; this replaces nothing there.  Error if no backward
- * was issued yet (or the last one ran inside a stream capture, where no event is recorded). */
+ * was issued on this device yet (or the last one ran inside a stream capture, where no event is recorded). */
 int mvh_vae_wait_dense_grads(mvh_stream_t stream);
+
+/* ---- the asynchronous launcher (csrc/launcher.hip) ---------------------------------------------------------------
+ * The reference's train loop (main.py:74-81: optimizer.zero_grad() -> model(...) -> loss.backward() -> optimizer.step())
+ * drives this library from ONE Python thread, and on this path that thread is the bottleneck: ~0.35 ms of kernel-launch
+ * calls per step inside mvh_vae_forward / mvh_vae_backward, then ~0.35 ms of torch.optim.Adam's Python, for ~0.45 ms of
+ * GPU work.  A launcher owns a worker thread and a stream S of its own; mvh_vae_forward_async / mvh_vae_backward_async
+ * take the arguments of the synchronous entries (copies of the descriptor and the pointer tables are made), hand the
+ * launch sequence to that thread and return at once.  Stream semantics are those of the synchronous call on
+ * `user_stream`: the job starts behind everything enqueued on `user_stream` before the call (an event), and
+ * `user_stream` continues only once the job's work has finished on the GPU (hipStreamWaitValue64 on a ticket the job's
+ * last packet writes) -- so a later consumer of an output, or a later allocation that reuses a freed input, is ordered
+ * behind the job.  The CALLER keeps every buffer a job touches allocated until that point (the Python binding holds
+ * references to the tensors of the last few jobs).  S and the worker's gradient lanes are created at the highest stream
+ * priority: the runtime pools hardware queues per priority, so none of them can sit behind the caller's blocked stream.
+ * A job's failure is kept and returned by the next call on the launcher (mvh_last_error carries its message).
+ * mvh_launcher_supported: 1 if the current device has hipStreamWaitValue64 (hipDeviceAttributeCanUseStreamWaitValue).
+ * mvh_launcher_sync: the calling host thread waits until the worker has enqueued everything handed over so far
+ * (host-side only; the GPU work is then ordinary stream work).  The reference has no counterpart: it replaces nothing
+ * there, it removes host time from the loop the reference drives. */
+typedef struct mvh_launcher mvh_launcher_t;
+int mvh_launcher_supported(void);
+int mvh_launcher_create(mvh_launcher_t** out);
+int mvh_launcher_sync(mvh_launcher_t* launcher);
+int mvh_launcher_destroy(mvh_launcher_t* launcher);
+int mvh_vae_forward_async(mvh_launcher_t* launcher, mvh_stream_t user_stream, const mvh_vae_desc_t* desc,
+                          const float* const* params, const float* x, const float* y, const void* x_gt, int32_t gt_f64,
+                          const float* eps, const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,
+                          float* recon, float* kld, void* rec, float* z, float* y_hat, float* mu, float* logvar,
+                          void* ws, size_t ws_bytes);
+int mvh_vae_backward_async(mvh_launcher_t* launcher, mvh_stream_t user_stream, const mvh_vae_desc_t* desc,
+                           const float* const* params, float* const* grads, const float* x, const float* y,
+                           const void* x_gt, int32_t gt_f64, const float* eps, const float* drop_u, int32_t B,
+                           float log_sigma, const void* d_loss, const float* recon, const float* y_hat, const float* mu,
+                           const float* logvar, void* ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

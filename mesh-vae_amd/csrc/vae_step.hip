@@ -5,6 +5,7 @@
 // autograd graph.  The weight-gradient kernels depend only on (layer input, layer dout), so the
 // backward forks them onto a side stream and the critical path is just the dX chain; the fork /
 // join uses events only, so the whole step is capturable into one hipGraph.
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -169,10 +170,25 @@ struct SideStream {
   bool tstack_armed = false;     // requested: the next mvh_vae_forward on (tstack_x, tstack_ws) launches it
 };
 
-// Per host thread: the step engine may be driven by several enqueue threads (one per chain of
-// meshes, engine.py TrainStep n_micro > 1); each gets its own side stream and event ring.
+// ONE set of gradient lanes per DEVICE, shared by every host thread, behind a per-device lock that an entry point holds for
+// the whole of its launch sequence.  (They used to be per host thread.  MEASURED, round 4, tools/stream_probe.py: a forward
+// enqueued by one thread and its backward by another -- exactly what torch.autograd does with the module path, whose
+// backward runs on the engine's device thread -- took 1.07-1.6 ms per step instead of 0.49 as soon as the second thread's
+// lanes had hardware queues of their own: beyond four busy hardware queues this GPU / driver stalls single launches for
+// ~10 ms.  GPU_MAX_HW_QUEUES = 3 made the same test 0.49 ms again.  With shared lanes a process has three busy queues
+// however many threads drive it.)  Threads that enqueue concurrently (TrainStep n_micro > 1) take turns.
+static std::mutex g_lane_mu[16];
+struct LaneLock {
+  std::unique_lock<std::mutex> lk;
+  LaneLock() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    lk = std::unique_lock<std::mutex>(g_lane_mu[dev]);
+  }
+};
+// (caller holds the device's LaneLock)
 static SideStream* side_for_device() {
-  static thread_local SideStream side[16];
+  static SideStream side[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream& s = side[dev];
@@ -331,8 +347,10 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     cur = F(p.encP[i]);
     // the armed first-layer stack (mvh_vae_backward_prefetch) starts behind encoder stage `prefetch_at` (debug switch,
     // default 0; MEASURED 0 .. 3 on one box: 553 .. 555 us per step, no difference)
-    if (i == min(max(dbg().prefetch_at, 0), n - 1) && phases == kPhAll)
+    if (i == min(max(dbg().prefetch_at, 0), n - 1) && phases == kPhAll) {
+      LaneLock lanes;
       TRY(run_armed_prefetch(side_for_device(), (hipStream_t)stream, d, p, x, ws, B));
+    }
   }
   if (phases & kPhEnc) {
     MVH_RANGE("fwd enc_lin");
@@ -427,6 +445,7 @@ extern "C" int mvh_vae_backward_prefetch(mvh_stream_t stream, const mvh_vae_desc
   StepPlan p;
   TRY(build_plan(d, B, p));
   MVH_REQUIRE(x && ws && ws_bytes >= p.total, "vae_backward_prefetch: null tensor or workspace too small");
+  LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward_prefetch: could not create the side stream");
   side->tstack_pending = side->tstack_armed = false;
@@ -468,6 +487,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   const int n = p.n;
   ParamIdx ix{n};
   hipStream_t main = (hipStream_t)stream;
+  LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward: could not create the side stream");
   hipStream_t sstream = side_stream ? (hipStream_t)side_stream : side->stream;
@@ -849,6 +869,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
 }
 
 extern "C" int mvh_vae_wait_dense_grads(mvh_stream_t stream) {
+  LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_wait_dense_grads: no device");
   MVH_REQUIRE(side->dense_recorded, "vae_wait_dense_grads: no mvh_vae_backward was issued from this thread on this device");

@@ -13,6 +13,26 @@ import os
 # package, or set the variable, before the first torch.cuda call).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+
+def _hip_started():
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# The asynchronous launcher (csrc/launcher.hip) leaves hipStreamWaitValue64 waits on the caller's stream.  By default the
+# runtime executes such a wait as a SHADER that spins on a compute unit for as long as the job runs -- measured: the step's
+# kernels then take 0.75 instead of 0.49 ms (profiles/r04_async_probe.txt) --; GPU_STREAMOPS_CP_WAIT=1 makes the command
+# processor wait instead (0.55 ms).  Like the queue count it is read when the HIP runtime initialises, so the launcher is
+# only used when the variable was in place by then: set by the caller, or set here before the first torch.cuda call.
+_cp_preset = os.environ.get("GPU_STREAMOPS_CP_WAIT")
+_started = _hip_started()
+os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
+CP_WAIT = (_cp_preset == "1") or (_cp_preset is None and not _started)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MESHVAE_LIB lets a benchmark A/B two builds of the library in one process-per-run session
 LIB_PATH = os.environ.get("MESHVAE_LIB") or os.path.join(_HERE, "libmeshvae_hip.so")
@@ -53,7 +73,7 @@ class VaeDesc(ctypes.Structure):
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
 STORAGE_F32, STORAGE_BF16 = 0, 1
-ABI_VERSION = 300   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
+ABI_VERSION = 310   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 
@@ -104,6 +124,12 @@ SIGNATURES = {
     "mvh_vae_forward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
     "mvh_vae_backward": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z, _P]),
     "mvh_vae_backward_prefetch": (ctypes.c_int, [_P, ctypes.POINTER(VaeDesc), _P, _I, _P, _Z, _P]),
+    "mvh_launcher_supported": (ctypes.c_int, []),
+    "mvh_launcher_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "mvh_launcher_sync": (ctypes.c_int, [_P]),
+    "mvh_launcher_destroy": (ctypes.c_int, [_P]),
+    "mvh_vae_forward_async": (ctypes.c_int, [_P, _P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
+    "mvh_vae_backward_async": (ctypes.c_int, [_P, _P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z]),
     "mvh_vae_loss_bwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 4),
 }
 
@@ -135,6 +161,37 @@ def check(rc):
     if rc != 0:
         cls = MeshVaeHipUnsupported if rc == 3 else MeshVaeHipError
         raise cls(f"libmeshvae_hip error {rc}: {lib().mvh_last_error().decode()}")
+
+
+_launchers = {}
+
+
+def launcher(device_index):
+    """The asynchronous launcher of a device (csrc/launcher.hip; one per process and device, created on first use and
+    destroyed at interpreter exit), or None when the device has no hipStreamWaitValue64 / MESHVAE_ASYNC=0."""
+    if device_index in _launchers:
+        return _launchers[device_index]
+    handle = None
+    mode = os.environ.get("MESHVAE_ASYNC", "1")            # "0": never; "force": even without the command-processor wait
+    if mode != "0" and (CP_WAIT or mode == "force"):
+        import torch
+        with torch.cuda.device(device_index):
+            if lib().mvh_launcher_supported():
+                h = ctypes.c_void_p()
+                check(lib().mvh_launcher_create(ctypes.byref(h)))
+                handle = h
+                if not _launchers:
+                    import atexit
+                    atexit.register(_destroy_launchers)
+    _launchers[device_index] = handle
+    return handle
+
+
+def _destroy_launchers():
+    for k, h in list(_launchers.items()):
+        if h is not None:
+            lib().mvh_launcher_destroy(h)
+        _launchers[k] = None
 
 
 class debug_switch:

@@ -588,8 +588,13 @@ class NativeStep:
                     p.grad = torch.zeros_like(p)
         PtrArr = ctypes.c_void_p * len(self.params)
         self._P = PtrArr(*[p.data_ptr() for p in self.params])
-        self.grads = grads if grads is not None else [p.grad for p in self.params]
-        self._G = PtrArr(*[g.data_ptr() for g in self.grads])
+        if isinstance(grads, str) and grads == "external":
+            # the caller hands a gradient table to run_backward per call (the module path's autograd node): this object
+            # owns none, and the entry points that would use one refuse
+            self.grads, self._G = None, None
+        else:
+            self.grads = grads if grads is not None else [p.grad for p in self.params]
+            self._G = PtrArr(*[g.data_ptr() for g in self.grads])
         self.ws_bytes = L.mvh_vae_step_ws_bytes(ctypes.byref(d), batch)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
         B, C, Z = batch, net.num_class, net.z
@@ -608,6 +613,8 @@ class NativeStep:
         """loss.backward() for the forward this object ran last (activations live in its workspace): the gradient
         of every parameter times the scalar `d_loss` (a 0-d device tensor of the loss dtype) goes to `self.grads`."""
         L = lib()
+        if self._G is None:
+            raise RuntimeError("this NativeStep has no gradient table of its own (grads='external'): use run_backward")
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         f64 = int(x_gt.dtype == torch.float64)
         with torch.cuda.device(self.dev):
@@ -649,7 +656,51 @@ class NativeStep:
 
     def _refresh_pointers(self):
         for i, p in enumerate(self.params):
-            self._P[i], self._G[i] = p.data_ptr(), self.grads[i].data_ptr()
+            self._P[i] = p.data_ptr()
+            if self._G is not None:
+                self._G[i] = self.grads[i].data_ptr()
+
+    def refresh_param_pointers(self):
+        """The parameter table only (the module path hands its own gradient table to run_backward): one list of
+        data_ptr() calls, written to the ctypes array only when a parameter moved (load_state_dict copies in place;
+        .to(), FlatParams or an assignment to p.data re-home it)."""
+        ptrs = [p.data_ptr() for p in self.params]
+        if ptrs != getattr(self, "_P_seen", None):
+            self._P[:] = ptrs
+            self._P_seen = ptrs
+
+    def run_forward(self, x, x_gt, y_f, eps, drop_u, outs, launcher=None):
+        """mvh_vae_forward into caller-provided output tensors `outs` = (loss, correct, recon, kld, rec, z_, y_hat, mu,
+        logvar) -- loss / rec of x_gt's dtype.  launcher: the device's asynchronous launcher (meshvae_hip.launcher) or
+        None for the synchronous call on the current stream; stream semantics are the same either way."""
+        L = lib()
+        loss, correct, recon, kld, rec, z_, y_hat, mu, logvar = outs
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        args = (ctypes.byref(self.desc), self._P, x.data_ptr(), y_f.data_ptr(), x_gt.data_ptr(),
+                int(x_gt.dtype == torch.float64), ptr(eps), ptr(drop_u), self.B, self.log_sigma, loss.data_ptr(),
+                correct.data_ptr(), recon.data_ptr(), kld.data_ptr(), rec.data_ptr(), z_.data_ptr(), y_hat.data_ptr(),
+                mu.data_ptr(), logvar.data_ptr(), self.ws.data_ptr(), self.ws_bytes)
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            if launcher is not None:
+                check(L.mvh_vae_forward_async(launcher, st, *args))
+            else:
+                check(L.mvh_vae_forward(st, *args))
+
+    def run_backward(self, x, x_gt, y_f, eps, drop_u, d_loss, recon, y_hat, mu, logvar, G, launcher=None):
+        """mvh_vae_backward for the forward this object ran last, gradients to the pointer table `G` (a ctypes array
+        of one address per parameter, state_dict order)."""
+        L = lib()
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        args = (ctypes.byref(self.desc), self._P, G, x.data_ptr(), y_f.data_ptr(), x_gt.data_ptr(),
+                int(x_gt.dtype == torch.float64), ptr(eps), ptr(drop_u), self.B, self.log_sigma, ptr(d_loss),
+                recon.data_ptr(), y_hat.data_ptr(), mu.data_ptr(), logvar.data_ptr(), self.ws.data_ptr(), self.ws_bytes)
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            if launcher is not None:
+                check(L.mvh_vae_backward_async(launcher, st, *args))
+            else:
+                check(L.mvh_vae_backward(st, *args, self.side.cuda_stream if self.side is not None else None))
 
     def _outs(self, dtype):
         if dtype not in self._loss:
@@ -662,6 +713,8 @@ class NativeStep:
         (loss, correct, recon, [kld, rec, z_], y_hat) exactly like cheb_VAE.forward."""
         import ctypes
         L = lib()
+        if backward and self._G is None:
+            raise RuntimeError("this NativeStep has no gradient table of its own (grads='external'): use run_backward")
         x, x_gt = x.contiguous(), x_gt.contiguous()
         if y.dtype == torch.float32 and y.is_contiguous() and y.device == self.dev:
             y_f = y                      # already what the kernels read: no per-step conversion launch

@@ -30,19 +30,27 @@ LOG_SIGMA = float(torch.nn.functional.softplus(torch.tensor([7.0])) - 6.0)
 
 
 class _FusedModelFn(torch.autograd.Function):
-    """cheb_VAE.forward as one autograd node (see cheb_VAE._forward_fused).  Only `loss` is differentiable."""
+    """cheb_VAE.forward as one autograd node (see cheb_VAE._forward_fused).  Only `loss` is differentiable.
+
+    What the reference's loop does around it -- optimizer.zero_grad(); loss.backward(); optimizer.step() (main.py:74-81)
+    -- runs on the calling thread, so everything here is written for that thread's time: outputs are FRESH tensors the
+    native step writes directly (no clones), the gradients are views of one fresh flat buffer (autograd adopts them as
+    the parameters' .grad without a copy; a kept .grad is accumulated into, as for any node), nothing synchronises, and
+    the launch sequences themselves go to the device's asynchronous launcher when there is one (csrc/launcher.hip)."""
 
     @staticmethod
-    def forward(ctx, ent, x, x_gt, y, eps, drop_u, *params):
+    def forward(ctx, ent, lch, x, x_gt, y, eps, drop_u, *params):
         step = ent["step"]
-        loss, correct, recon, (kld, rec, z_), y_hat = step.forward_backward(x, x_gt, y, eps=eps, drop_u=drop_u,
-                                                                             backward=False)
-        y_f = y if (y.dtype == torch.float32 and y.is_contiguous()) else step.y_f.clone()
-        ctx.ent, ctx.gen = ent, ent["gen"]
-        ctx.saved = (x, x_gt, y_f, eps, drop_u)
-        outs = (loss.clone(), correct.clone(), recon.clone(), kld.clone(), rec.clone(), z_.clone(), y_hat.clone())
-        ctx.mark_non_differentiable(*outs[1:])
-        return outs
+        outs, y_f = ent["alloc"](x, x_gt, y)
+        step.run_forward(x, x_gt, y_f, eps, drop_u, outs, lch)
+        loss, correct, recon, kld, rec, z_, y_hat, mu, logvar = outs
+        ctx.ent, ctx.gen, ctx.lch = ent, ent["gen"], lch
+        ctx.saved = (x, x_gt, y_f, eps, drop_u, recon, y_hat, mu, logvar)
+        ent["keep"].append(ctx.saved + (loss, correct, kld, rec, z_))
+        res = (loss, correct, recon, kld, rec, z_, y_hat)
+        ctx.mark_non_differentiable(*res[1:])
+        ctx.set_materialize_grads(False)          # (no zero tensors for the six outputs nobody differentiates)
+        return res
 
     @staticmethod
     def backward(ctx, d_loss, *_):
@@ -51,16 +59,21 @@ class _FusedModelFn(torch.autograd.Function):
             raise RuntimeError("cheb_VAE fused forward: backward() must follow its own forward (the activations of an "
                                "earlier forward of this batch size were overwritten); set net.fused_step = False "
                                "to keep several graphs alive")
-        x, x_gt, y_f, eps, drop_u = ctx.saved
+        if d_loss is None:                         # (materialize_grads is off: loss did not reach the differentiated output)
+            return (None,) * (7 + len(ent["views"]))
+        x, x_gt, y_f, eps, drop_u, recon, y_hat, mu, logvar = ctx.saved
         step = ent["step"]
-        step.backward(x, x_gt, y_f, d_loss.contiguous(), eps=eps, drop_u=drop_u)
-        flat = ent["flat"].clone()                      # autograd may keep / accumulate into what it is handed
-        grads, off = [], 0
-        for name, p in zip(step.net._fused_names(), step.params):
-            g = flat[off:off + p.numel()].view_as(p)
-            off += -(-p.numel() // 64) * 64
-            grads.append(None if name.startswith("dec_lin_1.") else g)   # never used by the forward (reference :165)
-        return (None, None, None, None, None, None, *grads)
+        d_loss = d_loss.contiguous()
+        # a fresh flat gradient buffer per backward: autograd may keep what it is handed as .grad, and the caller may
+        # keep THAT over any number of steps (no zero_grad, gradient accumulation): nothing here is ever rewritten
+        flat = torch.empty(ent["numel"], dtype=torch.float32, device=x.device)
+        ent["G_np"][:] = ent["off_np"] + flat.data_ptr()
+        step.run_backward(x, x_gt, y_f, eps, drop_u, d_loss, recon, y_hat, mu, logvar, ent["G"], ctx.lch)
+        ent["keep"].append(ctx.saved + (flat, d_loss))
+        as_strided = flat.as_strided
+        # (dec_lin_1 is never used by the forward, reference :165: its gradient is None, its span of `flat` is not written)
+        return (None, None, None, None, None, None, None,
+                *[None if v is None else as_strided(v[0], v[1], v[2]) for v in ent["views"]])
 
 
 class cheb_VAE(torch.nn.Module):
@@ -204,6 +217,25 @@ class cheb_VAE(torch.nn.Module):
         return F_hip.vae_loss(recon_x, x, mu_z, logvar_z, y.to(torch.float32), y_hat, LOG_SIGMA)
 
     # ------------------------------------------------------------------ full step
+    def _host_eps(self, B, dev):
+        """The reparameterisation noise exactly as the reference draws it -- torch.normal on the HOST default generator
+        (:316) -- but moved with an asynchronous copy from a small ring of pinned buffers: the reference's pageable
+        `.to(device)` makes the host wait for everything queued on the stream, once per step."""
+        rings = self.__dict__.setdefault("_eps_rings", {})
+        ring = rings.get(B)
+        if ring is None:
+            if len(rings) >= 4:
+                rings.pop(next(iter(rings)))
+            ring = rings[B] = {"i": 0, "slots": [(torch.empty(B, self.z).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
+        buf, ev = ring["slots"][ring["i"]]
+        ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        ev.synchronize()                                   # the copy that read this buffer four draws ago
+        torch.normal(mean=0, std=1, size=(B, self.z), out=buf)
+        eps = torch.empty(B, self.z, device=dev)
+        eps.copy_(buf, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        return eps
+
     def _forward_fused(self, x, x_gt, y, m_type):
         """The whole forward as ONE autograd node over the native step (mvh_vae_forward / mvh_vae_backward):
         what `loss.backward()` in the reference's train loop (main.py:80) then triggers is a single C++ launch
@@ -216,38 +248,76 @@ class cheb_VAE(torch.nn.Module):
             provider = getattr(self, "_eps_provider", None)
             eps = provider(B, self.z, dev) if provider is not None else None
             if eps is None:                # no engine buffer for this batch size: host generator, as the reference (:316)
-                eps = torch.normal(mean=0, std=1, size=(B, self.z)).to(dev)
+                eps = self._host_eps(B, dev)
         drop_u = torch.rand(B * step.u_cols, device=dev) if (self.training and self.dropout.p > 0.0) else None
         ent["gen"] += 1
+        x, x_gt = x.contiguous(), x_gt.contiguous()
+        # (inside a stream capture -- TrainStep(native=False, use_graph=True) -- the launches must be recorded by the
+        #  capturing thread on the capturing stream: no launcher there)
+        lch = ent["launcher"] if (ent["launcher"] is not None and not torch.cuda.is_current_stream_capturing()) else None
         if not torch.is_grad_enabled():              # evaluate loops (main.py:129): the same launch sequence, forward only
-            loss, correct, recon, (kld, rec, z_), y_hat = step.forward_backward(x.contiguous(), x_gt.contiguous(), y,
-                                                                                 eps=eps, drop_u=drop_u, backward=False)
-            return loss.clone(), correct.clone(), recon.clone(), [kld.clone(), rec.clone(), z_.clone()], y_hat.clone()
-        outs = _FusedModelFn.apply(ent, x.contiguous(), x_gt.contiguous(), y, eps, drop_u, *step.params)
+            outs, y_f = ent["alloc"](x, x_gt, y)
+            step.run_forward(x, x_gt, y_f, eps, drop_u, outs, lch)
+            ent["keep"].append((x, x_gt, y_f, eps, drop_u) + outs)
+            loss, correct, recon, kld, rec, z_, y_hat = outs[:7]
+            return loss, correct, recon, [kld, rec, z_], y_hat
+        outs = _FusedModelFn.apply(ent, lch, x, x_gt, y, eps, drop_u, *step.params)
         loss, correct, recon, kld, rec, z_, y_hat = outs
         return loss, correct, recon, [kld, rec, z_], y_hat
 
     def _fused_entry(self, B, dev):
-        """Native step object (descriptor, workspace, gradient buffers) for batch size B, a few sizes cached."""
+        """Native step object (descriptor, workspace) for batch size B plus what the autograd node needs per call, a few
+        sizes cached."""
+        import collections
+        import ctypes
+
+        import numpy as np
+
+        import meshvae_hip
         from meshvae_hip.engine import NativeStep
         cache = self.__dict__.setdefault("_fused_cache", {})
         # net.storage = "bf16": the fused forward / backward keep the activations between the conv layers as bf16
         # (mvh_vae_desc_t.storage; fp32 accumulation, fp32 parameters) -- BASELINE configs[1] as worded.  Default fp32.
         storage = getattr(self, "storage", "f32")
-        B_key = (B, storage)
+        B_key = (B, storage, dev.index)
         ent = cache.get(B_key)
         if ent is None:
             if len(cache) >= 3:                      # (a workspace is ~12 MB per mesh: keep few batch sizes)
-                cache.pop(next(iter(cache)))
+                old = cache.pop(next(iter(cache)))
+                if old["launcher"] is not None:      # (its workspace may still be named by a queued job)
+                    meshvae_hip.check(meshvae_hip.lib().mvh_launcher_sync(old["launcher"]))
+            names = self._fused_names()
             params = [p for _, p in self.named_parameters()]
-            flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in params), dtype=torch.float32, device=dev)
-            views, off = [], 0
+            # gradients of one backward: views of ONE flat fp32 buffer, every tensor on a 256-byte boundary
+            offs, off = [], 0
             for p in params:
-                views.append(flat[off:off + p.numel()].view_as(p))
+                offs.append(off)
                 off += -(-p.numel() // 64) * 64
-            ent = cache[B_key] = {"step": NativeStep(self, B, grads=views, storage=storage), "flat": flat, "views": views,
-                                  "gen": 0}
-        ent["step"]._refresh_pointers()
+            views = [None if n.startswith("dec_lin_1.") else (tuple(p.shape), tuple(p.stride()), o)
+                     for n, p, o in zip(names, params, offs)]
+            # the step's own gradient table is unused on this path (run_backward gets `G`): no per-parameter buffers
+            step = NativeStep(self, B, grads="external", storage=storage)
+            G = (ctypes.c_void_p * len(params))()
+            N0, F0, Z, C = self.num_nodes[0], self.filters[0], self.z, self.num_class
+
+            def alloc(x, x_gt, y, B=B, dev=dev, N0=N0, F0=F0, Z=Z, C=C):
+                """Fresh output tensors of one forward (written by the native step) and y as the fp32 one-hot it reads."""
+                f32 = {"dtype": torch.float32, "device": dev}
+                y_f = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.to(torch.float32).contiguous()
+                lt = x_gt.dtype
+                return ((torch.empty((), dtype=lt, device=dev), torch.empty((), dtype=torch.int64, device=dev),
+                         torch.empty(B, N0, F0, **f32), torch.empty(B, **f32), torch.empty(B, dtype=lt, device=dev),
+                         torch.empty(B, Z, **f32), torch.empty(B, C, **f32), torch.empty(B, Z, **f32),
+                         torch.empty(B, Z, **f32)), y_f)
+            ent = cache[B_key] = {"step": step, "gen": 0, "numel": off, "views": views, "G": G,
+                                  "G_np": np.frombuffer(G, dtype=np.uint64),
+                                  "off_np": np.asarray(offs, dtype=np.uint64) * np.uint64(4), "alloc": alloc,
+                                  # the tensors of the last few calls stay referenced: a job handed to the asynchronous
+                                  # launcher names raw addresses, and the caller may drop its tensors (or empty the
+                                  # allocator's cache) before the worker thread has enqueued it
+                                  "keep": collections.deque(maxlen=6),
+                                  "launcher": meshvae_hip.launcher(dev.index) if getattr(self, "async_launch", True) else None}
+        ent["step"].refresh_param_pointers()
         return ent
 
     def _native_ok(self, t):
@@ -258,10 +328,9 @@ class cheb_VAE(torch.nn.Module):
         self.supervise = supervise
         x, batch_size = data.x, data.num_graphs          # data.edge_index is never used (reference :195)
         x = x.reshape(batch_size, -1, self.filters[0])
-        no_grad = not torch.is_grad_enabled()
         if (getattr(self, "fused_step", True) and x.is_cuda and x_gt.dtype in (torch.float32, torch.float64)
-                and (no_grad or (not x.requires_grad and not x_gt.requires_grad
-                                 and all(p.requires_grad for p in self.parameters())))):
+                and (not torch.is_grad_enabled() or (not x.requires_grad and not x_gt.requires_grad
+                                                     and self._all_params_require_grad()))):
             self._prepare()
             return self._forward_fused(x, x_gt, y, m_type)
         h = self.encoder(x)
@@ -269,3 +338,13 @@ class cheb_VAE(torch.nn.Module):
         x = self.decoder(z).reshape(batch_size, -1, self.filters[0])
         loss, correct, kld, rec_loss = self.loss_function(x_gt, x, z, x_mean, x_var, y, y_hat)
         return loss, correct, x, [kld, rec_loss, z_], y_hat
+
+    def _all_params_require_grad(self):
+        """(over a cached list: walking the module tree with .parameters() costs ~40 us per call)"""
+        ps = self.__dict__.get("_param_list")
+        if ps is None:
+            ps = self.__dict__["_param_list"] = [p for _, p in self.named_parameters()]
+        for p in ps:
+            if not p.requires_grad:
+                return False
+        return True
