@@ -34,6 +34,7 @@ struct BigArgs {
   long long plane;      // B * N * C
   const float* mask;    // MODE 0, optional: rows like `in`; an input element counts only where mask > 0 (ReLU backward)
   int with_t0;          // MODE 0: the (masked) input itself is stored as plane 0 and T_k as plane k (K planes)
+  int half_ids;         // TIMING ONLY (debug switch big_half_ids): 8 id bytes per vertex and order instead of 16
   int pm;               // the stack (MODE 0: tx, MODE 1: G) is PAIR-MAJOR: plane k = [B][C/2][N][2] (C even), so that a
                         // workgroup streams 8 contiguous bytes per vertex instead of 8-byte pieces of 64-byte rows --
                         // with row layout the 8 pair-workgroups of a mesh drift apart, every one of them pulls the whole
@@ -144,18 +145,21 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
     // neighbour ids: a ring of kBigRing vertices' 16-byte words stays in flight (an order needs 320 KB of them per
     // workgroup from L2; with two vertices ahead the CU had ~32 KB outstanding and an order took 14 us, all latency)
     uint4 ring[kBigRing];
+    auto ids_of = [&](int v) -> uint4 {
+      if (a.half_ids) {   // (timing experiment: the first four ids twice)
+        const uint2 h = reinterpret_cast<const uint2*>(a.ell)[2 * (v < N ? v : N - 1)];
+        return make_uint4(h.x, h.y, h.x, h.y);
+      }
+      return ellv[v < N ? v : N - 1];
+    };
 #pragma unroll
-    for (int j = 0; j < kBigRing; ++j) {
-      const int v = tid_k + kBigThreads * j;
-      ring[j] = ellv[v < N ? v : N - 1];
-    }
+    for (int j = 0; j < kBigRing; ++j) ring[j] = ids_of(tid_k + kBigThreads * j);
 #pragma unroll
     for (int j = 0; j < kBigVpt; ++j) {
       const int v = tid_k + kBigThreads * j;
       const uint4 id = ring[j % kBigRing];
       if (j + kBigRing < kBigVpt) {
-        const int vn = tid_k + kBigThreads * (j + kBigRing);
-        ring[j % kBigRing] = ellv[vn < N ? vn : N - 1];
+        ring[j % kBigRing] = ids_of(tid_k + kBigThreads * (j + kBigRing));
       }
       if (v < N) {
         const float2 n0 = pl[id.x & 0xFFFFu], n1 = pl[id.x >> 16], n2 = pl[id.y & 0xFFFFu], n3 = pl[id.y >> 16];
@@ -246,7 +250,7 @@ template <int MODE>
 static int big_launch(hipStream_t st, const mvh_csr_t* lap, const float* in, float* out, int B, int N, int C, int K,
                       bool pm, const float* mask = nullptr, bool with_t0 = false) {
   if (pm && (C & 1)) return fail(MVH_ERR_INVALID, "cheb_big: the pair-major stack needs an even channel count");
-  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, mask, with_t0 ? 1 : 0, pm ? 1 : 0};
+  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, mask, with_t0 ? 1 : 0, dbg().big_half_ids, pm ? 1 : 0};
   const size_t lds = (size_t)(N + 1) * 8;
   const int grid = ((B + 7) / 8) * 8 * ((C + 1) / 2);
   auto go = [&](auto kern) -> int {

@@ -84,3 +84,22 @@ CFG_5K = {"n_layers": 4, "num_conv_filters": [16, 16, 16, 32, 32], "polygon_orde
 def state_dict_from(npz):
     import torch
     return {str(k): torch.from_numpy(npz[f"sd/{k}"]) for k in npz["sd_keys"]}
+
+
+# Per-tensor bars for the gradients of the bf16-storage step against the reference's fp32 gradients at B = 4 (model_*.npz):
+# 2 x the figures MEASURED in round 4 (profiles/r04_bf16_gradient_table.txt; the error is storage rounding accumulated along
+# the backward chain, so it grows towards the first encoder layer), matched by longest prefix.  A flat 0.2 bar would
+# let a wrong summation order in one encoder kernel pass; these do not.
+GRAD_BARS = {
+    "5k": {"cheb.0.": 0.17, "cheb.1.": 0.125, "cheb.2.": 0.10, "cheb.3.": 0.035, "cheb_dec.0.": 0.016, "cheb_dec.": 0.007,
+           "classifier_layer.": 0.008, "z_mean.": 0.026, "z_log_var.": 0.035, "enc_lin.": 0.026, "dec_lin_2.": 0.04,
+           "dec_lin.": 0.045},
+    "tiny": {"cheb.": 0.0035, "cheb_dec.0.": 0.022, "cheb_dec.": 0.0025, "classifier_layer.": 0.0035, "z_mean.": 0.002,
+             "z_log_var.": 0.0015, "enc_lin.": 0.0025, "dec_lin_2.": 0.03, "dec_lin.": 0.035},
+}
+
+
+def grad_bar(which, name, scale=1.0):
+    table = GRAD_BARS[which]
+    best = max((k for k in table if name.startswith(k)), key=len)
+    return scale * table[best]

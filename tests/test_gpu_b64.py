@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, CFG_20K, ROOT
+from conftest import CFG_5K, CFG_20K, ROOT, grad_bar
 
 pytestmark = pytest.mark.gpu
 FWD_ATOL = 1e-4
@@ -102,7 +102,7 @@ def _oracle(cfg, topo_name, net, x, y, eps, drop_u, H, flat, dtype=torch.float32
                 z=zo.detach(), y_hat=yo.detach(), grads=ora.grads(), pre=ora.pre)
 
 
-def _relu_ties(nat, net, want, drop_u, tag, topo_name):
+def _relu_ties(nat, net, want, drop_u, tag, topo_name, max_ties=4):
     """Two fp32 evaluation orders disagree on the sign of a pre-activation that is zero to rounding (measured: B = 64
     meshes of the 5k model have 15 M ReLU inputs of magnitude O(1); about one per step lies within 1e-7 of zero, e.g.
     2.5e-8 in float64), and the ReLU derivative is discontinuous there, so ONE such element moves every upstream
@@ -139,8 +139,11 @@ def _relu_ties(nat, net, want, drop_u, tag, topo_name):
         assert worst <= 5e-6 * scale, (site, "ReLU sign differs at a pre-activation that is NOT a tie", worst, scale)
         pins[site] = torch.where(diff, ours, theirs)
         notes.append(f"{site}: {int(diff.sum())} tie(s), |pre| <= {worst:.1e} of max {scale:.1e}")
-    if notes:
-        print(f"[{tag}] ReLU ties pinned to this library's decision: " + "; ".join(notes))
+    n_ties = sum(int(x.split(": ")[1].split(" ")[0]) for x in notes)
+    print(f"[{tag}] ReLU ties: {n_ties} (bound {max_ties})" + (" -- pinned to this library's decision: " + "; ".join(notes) if notes else ""))
+    # the pinning bends the checker towards the product, so its use is counted: measured ~1 per 5k step at B = 64 (15 M ReLU
+    # inputs), a few dozen per 20k step; a kernel that started to disagree with the reference beyond rounding would show here
+    assert n_ties <= max_ties, (tag, n_ties, notes)
     return pins
 
 
@@ -218,7 +221,9 @@ def test_b64_bf16_step_against_fp32_step_and_oracle():
         rel = float((b16["grads"][k] - gref).norm()) / max(float(gref.norm()), 1e-12)
         cos = float(torch.nn.functional.cosine_similarity(b16["grads"][k].reshape(1, -1).double(), gref.reshape(1, -1).double()))
         assert cos > 0.99, (k, cos)
-        assert rel < (3e-2 if k.startswith("cheb_dec.") else 0.2), (k, rel)
+        # (test_gpu_bf16.GRAD_BARS: 2 x the per-tensor figures measured at B = 4; a batch of 64 averages the storage noise
+        #  of 16 x the meshes -- measured worst 2.0e-2 (cheb.0.weight) against 6.0e-2 at B = 4 -- so half of those bars)
+        assert rel < grad_bar("5k", k, 0.5), (k, rel)
         if rel > worst:
             worst, worst_k = rel, k
     print(f"[b64 bf16 5k] recon vs fp32 step: worst mesh {float(e_mesh.max()):.2e} of max|recon|; worst gradient rel {worst:.2e} ({worst_k})")
@@ -235,7 +240,7 @@ def test_b64_hires20k_step_matches_oracle_on_all_meshes():
     drop_u = torch.rand(B * (3 * H + flat), generator=g)
     nat, got = _native(net, B, x, y, eps, drop_u)
     want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat)
-    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k", "topology_20k.npz")
+    pins = _relu_ties(nat, net, want, drop_u, "b64 fp32 20k", "topology_20k.npz", max_ties=120)
     if pins:
         want = _oracle(CFG_20K, "topology_20k.npz", net, x, y, eps, drop_u, H, flat, pins=pins)
     # (the float64 run beside it -- this library ~1e-5, the reference's fp32 1-2e-6 from the exact answer at this size --

@@ -26,7 +26,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, ROOT, TINY_CFG
+from conftest import grad_bar,  CFG_5K, ROOT, TINY_CFG
 
 pytestmark = pytest.mark.gpu
 BF16_EPS = 2.0 ** -9            # half an ulp, relative
@@ -168,7 +168,7 @@ def test_bf16_train_step_against_reference_vectors_and_fp32_path(which, model_ti
         cos = float(torch.nn.functional.cosine_similarity(b16["grads"][k].reshape(1, -1).double(),
                                                           want.reshape(1, -1).double()))
         assert cos > 0.99, (k, cos)
-        assert rel < (3e-2 if k.startswith("cheb_dec.") else 0.2), (k, rel)
+        assert rel < grad_bar(which, k), (k, rel, grad_bar(which, k))
         if rel > worst:
             worst, worst_k = rel, k
     print(f"[bf16 {which}] gradient rel error vs reference / vs fp32 path: " + " ".join(table))
@@ -367,3 +367,107 @@ def test_bf16_level0_lane_moves_launches_only(B):
         assert torch.equal(res[lanes][0], res[0][0]) and torch.equal(res[lanes][1], res[0][1])
         for k, gref in res[0][2].items():
             assert torch.equal(res[lanes][2][k], gref), (lanes, k)
+
+
+class _Round(torch.autograd.Function):
+    """bf16 STORAGE of a tensor in the middle of an fp32 computation: the value and / or the gradient passing this point
+    are rounded to bf16 (round-to-nearest-even, what v_cvt_pk_bf16_f32 does) and widened again."""
+
+    @staticmethod
+    def forward(ctx, t, fwd, bwd):
+        ctx.bwd = bwd
+        return t.bfloat16().float() if fwd else t.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.bfloat16().float() if ctx.bwd else g), None, None
+
+
+def _emulated_bf16_step(net, x, x_gt, y, eps):
+    """The fp32 module-level ops (this library's fp32 kernels) with bf16 rounding inserted exactly where the bf16-storage
+    step stores a tensor (csrc/vae_step.hip: ConvIO::x / out / pooled / dout / dx / dx_pooled):
+      encoder stage i < n - 1 : pooled output and the gradient arriving at it (encP[i], g_encP[i]);
+      first un-pooling        : value only (decU[0]; its gradient goes to the fp32 dense head unrounded);
+      decoder stage i < n - 1 : the un-pooled tensor U c_i is built from the UNROUNDED c_i in LDS and stored once
+                                (decU[i + 1]: value); the gradient arriving at c_i is U^T dX_{i+1}, stored once (g_decC[i]);
+      last decoder stage      : value (decC[n - 1], read by the final layer) and gradient (g_decC[n - 1])."""
+    from meshvae_hip import functional as F
+    from models.cheb_VAE import LOG_SIGMA
+    q = _Round.apply
+    n, B = net.n_layers, x.shape[0]
+    h = x
+    for i in range(n):
+        h = F.surface_pool(F.cheb_conv(h, net.cheb[i].weight, net.cheb[i].bias, net._lap[i], relu=True), net._down[i])
+        if i < n - 1:
+            h = q(h, True, True)
+    h = F.linear(h.reshape(B, -1), net.enc_lin.weight, net.enc_lin.bias, relu=True)
+    y_hat, mu, logvar, z_, z = F.latent_head(h, y.float(), net.classifier_layer.weight, net.classifier_layer.bias,
+                                             net.z_mean.weight, net.z_mean.bias, net.z_log_var.weight, net.z_log_var.bias,
+                                             eps=eps)
+    d = F.linear(z, net.dec_lin.weight, net.dec_lin.bias, relu=True)
+    d = F.linear(d, net.dec_lin_2.weight, net.dec_lin_2.bias, relu=True).reshape(B, -1, net.filters[-1])
+    u = q(F.surface_pool(d, net._up[-1]), True, False)
+    for i in range(n):
+        c = F.cheb_conv(u, net.cheb_dec[i].weight, net.cheb_dec[i].bias, net._lap[n - i - 1], relu=True)
+        if i < n - 1:
+            u = q(F.surface_pool(q(c, False, True), net._up[-i - 2]), True, False)
+    c = q(c, True, True)
+    recon = F.cheb_conv(c, net.cheb_dec[n].weight, None, net._lap_final, relu=False)
+    loss, correct, kld, rec = F.vae_loss(recon, x_gt, mu, logvar, y.float(), y_hat, LOG_SIGMA)
+    return loss, recon, z_
+
+
+@pytest.mark.parametrize("which,B", [("tiny", 5), ("5k", 4)])
+def test_bf16_step_against_fp32_kernels_with_emulated_storage(which, B):
+    """the loose whole-model bars above compare bf16 storage with the fp32 reference, i.e. they contain the
+    storage noise itself (6-8 % at the first encoder layer).  Here that noise is taken OUT: the fp32 kernels are fed the
+    same bf16-rounded activations and gradients (_emulated_bf16_step), so what is left between the two runs is kernel
+    arithmetic -- summation order, and stored values that land on the other side of a rounding boundary because of it.
+    The bf16 step runs its general LDS kernels at every level (debug switch no_l0h: the 5k level's matrix-pipe kernels
+    additionally round the WEIGHTS and T_k to bf16, which is not storage; they are held against this form by
+    test_bf16_step_matrix_pipe_kernels_against_the_unpack_form).  MEASURED (round 4, tiny and 5k): the two runs agree
+    BITWISE -- recon, z, loss and every gradient -- except the first layer's weight gradient (1.6e-7: the step takes it from
+    the saved Chebyshev stack, the module op from the recurrence kernel).  The bf16 kernels are the fp32 kernels plus the
+    storage rounding, nothing else; the bars say so: forward outputs equal, gradients within 2e-6 relative."""
+    from meshvae_hip import debug_switch
+    from meshvae_hip.engine import NativeStep
+    dev = _dev()
+    N = 162 if which == "tiny" else 4998
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, N, 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+    net = _model(which, dev).train()
+    net._prepare()
+    with debug_switch("no_l0h", 1):
+        nat = NativeStep(net, B, storage="bf16")
+        loss, _, recon, (_, _, z_), _ = nat.forward_backward(x, x, y, eps=eps, drop_u=None)
+        torch.cuda.synchronize()
+    got = (float(loss), recon.clone(), z_.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    ref = _model(which, dev).train()
+    ref._prepare()
+    ref.fused_step = False
+    l2, r2, z2 = _emulated_bf16_step(ref, x, x, y, eps)
+    l2.backward()
+    e_recon = float((got[1] - r2.detach()).abs().max() / r2.detach().abs().max())
+    e_z = float((got[2] - z2.detach()).abs().max())
+    e_loss = abs(got[0] - float(l2)) / abs(float(l2))
+    table, bad = [], []
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        rel = float((got[3][k] - p.grad).norm() / p.grad.norm().clamp_min(1e-20))
+        table.append(f"{k}={rel:.1e}")
+        if not rel < 2e-6:
+            bad.append((k, rel))
+    print(f"[bf16 vs emulated storage, {which}] recon {e_recon:.2e} of max|recon|, z {e_z:.2e}, loss rel {e_loss:.2e}; gradients: "
+          + " ".join(table))
+    assert torch.equal(got[1], r2.detach()) and torch.equal(got[2], z2.detach()) and got[0] == float(l2), (e_recon, e_z, e_loss)
+    assert not bad, bad
+    # ... and the emulation is not vacuous: without the rounding the same fp32 ops are 10 x further away
+    plain = _model(which, dev).train()
+    plain.fused_step = False
+    from meshvae_hip.engine import _Batch
+    plain._eps_provider = lambda B_, Z_, d_: eps
+    lp = plain(_Batch(x), x, y, m_type="train")
+    assert float((got[1] - lp[2].detach()).abs().max() / r2.detach().abs().max()) > 1e-4
