@@ -940,7 +940,8 @@ static int try_xty_small(hipStream_t st, const float* x, const float* dpre, floa
   if (grid > kXtyGrid) grid = kXtyGrid;
   if (!partial || part_bytes < (size_t)grid * nout * sizeof(float)) return MVH_OK;
   const int xb = x_bf16 ? 1 : 0;
-  if (Cout == 3) hipLaunchKernelGGL((k_xty_small<3>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin, xb);
+  if (dbg().skip_xty) {}   // TIMING ONLY (results invalid): what would S from the loss launch be worth?
+  else if (Cout == 3) hipLaunchKernelGGL((k_xty_small<3>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin, xb);
   else hipLaunchKernelGGL((k_xty_small<4>), dim3(grid), dim3(256), 0, st, x, dpre, partial, rows, Cin, xb);
   MVH_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_xty_finish, dim3(1), dim3(1024), 0, st, partial, grid, nout, Cin * Cout, S, db);

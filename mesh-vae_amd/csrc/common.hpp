@@ -124,6 +124,7 @@ struct DebugCfg {
   int no_src3 = 0;         // 1: the final layer's dX writes all rows of its input gradient (no lazy rows in the 5k level's dX / dW)
   int no_final_fuse = 0;   // 1: the final layer's per-vertex map as its own launch (k_cheb_contract) instead of inside the loss launch
   int skip_conv_dw = 0;    // TIMING ONLY, results invalid: no conv weight-gradient launches on the side lane (how long is the main chain alone?)
+  int skip_xty = 0;        // TIMING ONLY, results invalid: the final layer's S = x^T dout pass (k_xty_small) is not launched
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
