@@ -410,8 +410,11 @@ int mvh_vae_wait_dense_grads(mvh_stream_t stream);
  * `user_stream` continues only once the job's work has finished on the GPU (hipStreamWaitValue64 on a ticket the job's
  * last packet writes) -- so a later consumer of an output, or a later allocation that reuses a freed input, is ordered
  * behind the job.  The CALLER keeps every buffer a job touches allocated until that point (the Python binding holds
- * references to the tensors of the last few jobs).  S and the worker's gradient lanes are created at the highest stream
- * priority: the runtime pools hardware queues per priority, so none of them can sit behind the caller's blocked stream.
+ * references to the tensors of the last few jobs).  S is created at the highest stream priority: the runtime pools
+ * hardware queues per priority, so S can never sit behind the caller's blocked stream in a shared queue.  The value
+ * wait should run on the command processor (environment GPU_STREAMOPS_CP_WAIT=1, read when the HIP runtime starts): the
+ * runtime's default is a shader that spins on a compute unit for as long as the job runs (measured: the step's kernels
+ * then take 0.75 instead of 0.55 ms); the Python binding only uses the launcher when that variable was in place in time.
  * A job's failure is kept and returned by the next call on the launcher (mvh_last_error carries its message).
  * mvh_launcher_supported: 1 if the current device has hipStreamWaitValue64 (hipDeviceAttributeCanUseStreamWaitValue).
  * mvh_launcher_sync: the calling host thread waits until the worker has enqueued everything handed over so far

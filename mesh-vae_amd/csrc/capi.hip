@@ -46,6 +46,8 @@ static const DebugKey kDebugKeys[] = {
     {"dw_tie_x", &DebugCfg::dw_tie_x},           {"roctx", &DebugCfg::roctx},
     {"no_src3", &DebugCfg::no_src3},             {"skip_conv_dw", &DebugCfg::skip_conv_dw},
     {"big_half_ids", &DebugCfg::big_half_ids},     {"skip_xty", &DebugCfg::skip_xty},
+    {"sched", &DebugCfg::sched},                   {"sched_lane", &DebugCfg::sched_lane},
+    {"sched_hold", &DebugCfg::sched_hold},
     {"no_final_fuse", &DebugCfg::no_final_fuse}, {"fork_small", &DebugCfg::fork_small},
     {"l0_lane", &DebugCfg::l0_lane},             {"l0_lane_any", &DebugCfg::l0_lane_any},
     {"l0_lane_bf", &DebugCfg::l0_lane_bf},       {"l0_hold", &DebugCfg::l0_hold},

@@ -124,6 +124,9 @@ struct DebugCfg {
   int no_src3 = 0;         // 1: the final layer's dX writes all rows of its input gradient (no lazy rows in the 5k level's dX / dW)
   int no_final_fuse = 0;   // 1: the final layer's per-vertex map as its own launch (k_cheb_contract) instead of inside the loss launch
   int skip_conv_dw = 0;    // TIMING ONLY, results invalid: no conv weight-gradient launches on the side lane (how long is the main chain alone?)
+  int sched = 0;           // 1: the conv weight-gradient items follow sched_lane / sched_hold instead of the built-in schedule (tools/sched_search.py)
+  int sched_lane = 0;      // bit k: item k (final layer, dec stages last to first, enc stages last to first) on the dense lane
+  int sched_hold = 0;      // base-4 digit k: forks of the chain item k lets pass before it is launched
   int skip_xty = 0;        // TIMING ONLY, results invalid: the final layer's S = x^T dout pass (k_xty_small) is not launched
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)

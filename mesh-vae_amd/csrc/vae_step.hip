@@ -538,6 +538,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     const float* tx;                        // T_k stack kept by the forward (big levels), else null
     ConvIO io;
     bool to_dense;                          // run on the dense lane (behind whatever is queued there)
+    int hold = 0;                           // schedule override (debug switch sched): forks of the chain to let pass first
   };
   PendingDw pending[6];
   int n_pending = 0;
@@ -563,7 +564,77 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   PendingDw held;
   bool have_held = false;
   int held_forks = 0;
+  // one queued weight-gradient item on its lane (the conv lane, or the dense lane with that lane's scratch; split > 1: the
+  // 5k level's kernel in that many part-batch launches, ConvIO::dw_split)
+  auto launch_one = [&](PendingDw& w, bool on_dense, int split) -> int {
+    bool deferred = false, fused = false;
+    hipStream_t sstream = on_dense ? dstream : sstream_conv;      // (shadows: this item's lane)
+    void* ss = on_dense ? ss2 : ss_conv;
+    const size_t ss_bytes = on_dense ? p.scratch2_bytes : p.scratch_bytes;
+    if (split > 1) w.io.dw_split = split;
+    const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
+    const float* dout = w.dout;
+    if (w.dout_pool) {
+      TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, w.tx, nullptr, w.dW, w.db, B, w.N,
+                             w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, w.dout_pool, &fused, w.bits,
+                             nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
+                             &deferred, nullptr, nullptr, w.io));
+      MVH_REQUIRE(fused || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the weight-gradient kernel");
+      if (!fused) {  // not eligible: explicit un-pooling on this lane, then the plain call below
+        TRY(mvh_pool_bwd((mvh_stream_t)sstream, w.unpool_t, w.dout, w.unpooled, B, w.cout));
+        dout = w.unpooled;
+      }
+    }
+    if (!fused)
+      TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, w.tx, nullptr, w.dW, w.db, B, w.N,
+                             w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
+                             can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred,
+                             nullptr, nullptr, w.io));
+    if (deferred) ++red.n;
+    return MVH_OK;
+  };
+  // ---- schedule override (debug switch sched = 1; A/B tooling, tools/sched_search.py): every conv weight-gradient item k
+  // (call order: final layer, decoder stages last to first, encoder stages last to first) takes its lane from bit k of
+  // sched_lane (1 = dense lane) and lets sched_hold's k-th base-4 digit forks of the chain pass before it is launched;
+  // items that come due at the same fork share it.  Results are those of the default schedule (launch order only).
+  const bool sched_on = dbg().sched != 0 && sstream != main && dstream != main && dstream != sstream && p.scratch_side2 != kNoBits;
+  PendingDw heldv[12];
+  int n_heldv = 0, sched_item = 0;
+  auto sched_tick = [&](bool also_dense, bool final) -> int {
+    int due[12], n_due = 0;
+    bool any_conv = false, any_dense = also_dense;
+    for (int h = 0; h < n_heldv; ++h) {
+      if (final || heldv[h].hold <= 0) {
+        due[n_due++] = h;
+        const bool l0 = l0_fits && heldv[h].N + 1 > 2048 && heldv[h].N + 1 <= 5120 && heldv[h].cin == 16 && heldv[h].cout == 16;
+        const bool dn = heldv[h].to_dense && (heldv[h].N + 1 <= 5120) && (l0 || heldv[h].N + 1 <= 2048 || heldv[h].cout > 4);
+        heldv[h].to_dense = dn;
+        (dn ? any_dense : any_conv) = true;
+      } else {
+        --heldv[h].hold;
+      }
+    }
+    if (n_due == 0 && !also_dense) return MVH_OK;
+    MVH_HIP(hipEventRecord(side->ev[ev], main));
+    if (any_conv) MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+    if (any_dense) MVH_HIP(hipStreamWaitEvent(dstream, side->ev[ev], 0));
+    ev = (ev + 1) % side->n_ev;
+    for (int d2 = 0; d2 < n_due; ++d2) {
+      PendingDw& w = heldv[due[d2]];
+      const bool l0 = l0_fits && w.N + 1 > 2048 && w.N + 1 <= 5120 && w.cin == 16 && w.cout == 16 && !w.dout_pool;
+      TRY(launch_one(w, w.to_dense, (l0 && w.to_dense && dbg().l0_lane > 1) ? dbg().l0_lane : 0));
+    }
+    int keep = 0;
+    for (int h = 0; h < n_heldv; ++h) {
+      bool launched = false;
+      for (int d2 = 0; d2 < n_due; ++d2) launched = launched || due[d2] == h;
+      if (!launched) heldv[keep++] = heldv[h];
+    }
+    n_heldv = keep;
+    return MVH_OK;
+  };
   auto flush_dw = [&](bool also_dense, bool force_held = false) -> int {  // one event for everything queued (+ the dense lane)
+    if (sched_on) return (also_dense || force_held) ? sched_tick(also_dense, force_held) : MVH_OK;
     if (n_pending == 0 && !also_dense && !have_held) return MVH_OK;
     const bool launch_held = have_held && (also_dense || force_held || n_pending == 0 || --held_forks <= 0);
     if (sstream != main) {
@@ -579,9 +650,6 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     if (launch_held) { pending[n_pending++] = held; have_held = false; }   // (pending has room: a flush comes at two items at the latest)
     for (int q = 0; q < n_pending; ++q) {
       PendingDw& w = pending[q];
-      bool deferred = false, fused = false;
-      hipStream_t sstream = sstream_conv;      // (shadows: this item's lane)
-      void* ss = ss_conv;
       const bool is_l0 = l0_split && w.N + 1 > 2048 && w.N + 1 <= 5120 && w.cin == 16 && w.cout == 16 && !w.dout_pool;
       if (is_l0 && !(launch_held && q == n_pending - 1)) {   // not yet: behind the next fork
         held = w;
@@ -589,29 +657,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
         held_forks = dbg().l0_hold < 1 ? 1 : dbg().l0_hold;
         continue;
       }
-      size_t ss_bytes = p.scratch_bytes;
-      if (lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1)) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; }
-      if (is_l0) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; w.io.dw_split = l0_split; }
-      else if (w.to_dense && w.N + 1 <= 5120) { sstream = dstream; ss = ss2; ss_bytes = p.scratch2_bytes; }
-      const bool can = w.part_off != kNoBits && red.n < (int)(sizeof(red.e) / sizeof(red.e[0]));
-      const float* dout = w.dout;
-      if (w.dout_pool) {
-        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, w.dout, w.tx, nullptr, w.dW, w.db, B, w.N,
-                               w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, w.dout_pool, &fused, w.bits,
-                               nullptr, can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes,
-                               &deferred, nullptr, nullptr, w.io));
-        MVH_REQUIRE(fused || !bf, "vae_backward: bf16 storage needs the fused un-pooling of the weight-gradient kernel");
-        if (!fused) {  // not eligible: explicit un-pooling on this lane, then the plain call below
-          TRY(mvh_pool_bwd((mvh_stream_t)sstream, w.unpool_t, w.dout, w.unpooled, B, w.cout));
-          dout = w.unpooled;
-        }
-      }
-      if (!fused)
-        TRY(cheb_conv_bwd_impl(sstream, w.lap, w.lap_t, w.xin, w.W, w.out, dout, w.tx, nullptr, w.dW, w.db, B, w.N,
-                               w.cin, w.cout, w.K, w.act, ss, ss_bytes, nullptr, nullptr, nullptr, w.bits, nullptr,
-                               can ? &red.e[red.n] : nullptr, can ? F(w.part_off) : nullptr, w.part_bytes, &deferred,
-                               nullptr, nullptr, w.io));
-      if (deferred) ++red.n;
+      const bool lane2_item = lane2 && w.N + 1 <= 2048 && (lane_toggle++ & 1);
+      TRY(launch_one(w, is_l0 || lane2_item || (w.to_dense && w.N + 1 <= 5120), is_l0 ? l0_split : 0));
     }
     n_pending = 0;
     return MVH_OK;
@@ -626,6 +673,16 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     {
       const int sk = dbg().skip_conv_dw;
       if (sk == 1 || (sk == 2 && N <= 400) || (sk == 3 && N > 2047) || (sk == 4 && N > 400 && N <= 2047)) return MVH_OK;
+    }
+    if (sched_on) {
+      const int k = sched_item++;
+      PendingDw w{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
+                  dout_pool, unpool_t, unpooled, tx, io, ((dbg().sched_lane >> k) & 1) != 0};
+      w.hold = (dbg().sched_hold >> (2 * k)) & 3;
+      MVH_REQUIRE(n_heldv < 12, "vae_backward: schedule override queue full");
+      heldv[n_heldv++] = w;
+      next_to_dense = false;
+      return sched_tick(false, false);
     }
     pending[n_pending++] = PendingDw{lap, lap_t, xin, W, out, dout, dW, db, N, cin, cout, K, act, bits, part_off, part_bytes,
                                      dout_pool, unpool_t, unpooled, tx, io,
@@ -851,7 +908,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     if (deferred) ++red.n;
   }
   TRY(flush_dw(false, true));   // the last fork also takes a level-0 item still held back (debug switch l0_hold >= 2)
-  MVH_REQUIRE(!have_held && n_pending == 0, "vae_backward: a weight-gradient launch was still queued at the join");
+  MVH_REQUIRE(!have_held && n_pending == 0 && n_heldv == 0, "vae_backward: a weight-gradient launch was still queued at the join");
   // join
   if (dstream != main && dstream != sstream) {
     MVH_HIP(hipEventRecord(side->ev[ev], dstream));

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Coordinate descent over the launch schedule of the conv weight-gradient items of the train step (debug switches
+sched / sched_lane / sched_hold, csrc/vae_step.hip): for each of the 8 items (final layer, decoder stages 3..0, encoder
+stages 3..1) the lane (conv / dense) and how many forks of the main chain it lets pass before it is launched.  Results are
+identical for every schedule (launch order only); the figure of merit is bench.py's ms_per_step.
+    python tools/sched_search.py [--passes 1] [--dtype f32] > gpurun_out/<tag>/sched_search.txt
+Every evaluation is one fresh bench.py process (300 timed steps); a candidate replaces the incumbent only if it wins a
+second, alternating pair as well (boxes drift by a few us within a minute)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ITEMS = ["final", "dec3", "dec2", "dec1", "dec0", "enc3", "enc2", "enc1"]
+
+
+def encode(cfg):
+    lane = sum(1 << k for k, (ln, _) in enumerate(cfg) if ln)
+    hold = sum(h << (2 * k) for k, (_, h) in enumerate(cfg))
+    return lane, hold
+
+
+def run(cfg, args, builtin=False):
+    env = dict(os.environ)
+    if builtin:
+        env.pop("MESHVAE_DEBUG", None)
+    else:
+        lane, hold = encode(cfg)
+        env["MESHVAE_DEBUG"] = f"sched=1,sched_lane={lane},sched_hold={hold}"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "30",
+                          "--prewarm-steps", "200", "--no-cpu-baseline", "--no-kernel-roofline", "--no-variants",
+                          "--dtype", args.dtype], env=env, capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        print("  FAILED:", out.stderr[-300:], flush=True)
+        return 1e9
+    return json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"] * 1e3
+
+
+def show(cfg):
+    return " ".join(f"{n}:{'D' if ln else 'c'}{h}" for n, (ln, h) in zip(ITEMS, cfg))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--passes", type=int, default=1)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--start", default="")          # "lane,hold" of a schedule to start from
+    ap.add_argument("--random", type=int, default=0, help="evaluate this many random schedules first (another basin?)")
+    args = ap.parse_args()
+    # the built-in schedule in this encoding: dec3 (the 5k level) and enc3 on the dense lane; final, dec3, dec1, enc3 wait one fork
+    cur = [(0, 1), (1, 1), (0, 0), (0, 1), (0, 0), (1, 1), (0, 0), (0, 0)]
+    if args.start:
+        lane, hold = (int(v) for v in args.start.split(","))
+        cur = [((lane >> k) & 1, (hold >> (2 * k)) & 3) for k in range(8)]
+    t0 = time.time()
+    b0 = run(cur, args, builtin=True)
+    c0 = run(cur, args)
+    b1 = run(cur, args, builtin=True)
+    c1 = run(cur, args)
+    print(f"built-in schedule {b0:.1f} {b1:.1f} us; the same through the override {c0:.1f} {c1:.1f} us  [{show(cur)}]", flush=True)
+    best = min(c0, c1)
+    if args.random:
+        import random
+        rng = random.Random(4)
+        seen = []
+        for i in range(args.random):
+            cand = [(0 if k == 0 else rng.randint(0, 1), rng.randint(0, 2)) for k in range(8)]
+            t = run(cand, args)
+            seen.append((t, cand))
+            if i % 10 == 9:
+                print(f"random {i + 1}: best so far {min(seen)[0]:.1f} us  [{time.time() - t0:.0f} s]", flush=True)
+        seen.sort(key=lambda e: e[0])
+        for t, cand in seen[:8]:
+            print(f"random top: {t:.1f} us  [{show(cand)}]", flush=True)
+        for t, cand in seen[:3]:                 # confirm the three best against the incumbent, alternating
+            t_cur, t2, t_cur2, t3 = run(cur, args), run(cand, args), run(cur, args), run(cand, args)
+            print(f"confirm [{show(cand)}]: incumbent {t_cur:.1f} {t_cur2:.1f}, candidate {t2:.1f} {t3:.1f}", flush=True)
+            if max(t2, t3) < min(t_cur, t_cur2) - 1.0:
+                cur, best = cand, min(t2, t3)
+                print("  -> ACCEPTED as the new incumbent", flush=True)
+                break
+    for ps in range(args.passes):
+        for k in range(8):
+            for ln in (0, 1):
+                for h in (0, 1, 2):
+                    if (ln, h) == cur[k] or (k == 0 and ln == 1):      # (the final layer's split path keeps the conv lane)
+                        continue
+                    cand = list(cur)
+                    cand[k] = (ln, h)
+                    t = run(cand, args)
+                    note = ""
+                    if t < best - 2.0:
+                        t_cur = run(cur, args)
+                        t2 = run(cand, args)
+                        note = f" | confirm: incumbent {t_cur:.1f}, candidate {t2:.1f}"
+                        if t2 < t_cur - 1.0:
+                            cur, best = cand, min(t, t2)
+                            note += " -> ACCEPTED"
+                        else:
+                            best = min(best, t_cur)
+                    print(f"pass {ps} {ITEMS[k]:5s} {'D' if ln else 'c'}{h}: {t:.1f} us (best {best:.1f}){note}  [{time.time() - t0:.0f} s]", flush=True)
+        lane, hold = encode(cur)
+        print(f"== after pass {ps}: {show(cur)}  sched_lane={lane} sched_hold={hold}  best {best:.1f} us", flush=True)
+    f0, f1 = run(cur, args), run(cur, args, builtin=True)
+    f2, f3 = run(cur, args), run(cur, args, builtin=True)
+    print(f"final: found {f0:.1f} {f2:.1f} us against built-in {f1:.1f} {f3:.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
