@@ -36,8 +36,10 @@ for _p in (ROOT, os.path.join(ROOT, "mesh-vae_amd")):
 # gradient lanes end up sharing the main chain's queue: measured 0.83 ms/step instead of 0.63 with a 1-rank
 # RCCL group (tools/dist_overhead.sh, dist_overhead2.sh).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# stream value waits of the asynchronous launcher on the command processor, not as a spinning shader (meshvae_hip/__init__.py)
-os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
+# stream value waits of the asynchronous launcher on the command processor, not as a spinning shader (meshvae_hip/__init__.py);
+# single-process runs only (the launcher serves variants.reference_loop; a multi-rank line never runs it)
+if os.environ.get("WORLD_SIZE", "1") in ("", "1"):
+    os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -28,10 +28,14 @@ def _hip_started():
 # kernels then take 0.75 instead of 0.49 ms (profiles/r04_async_probe.txt) --; GPU_STREAMOPS_CP_WAIT=1 makes the command
 # processor wait instead (0.55 ms).  Like the queue count it is read when the HIP runtime initialises, so the launcher is
 # only used when the variable was in place by then: set by the caller, or set here before the first torch.cuda call.
+# Single-process jobs only: a rank of a data-parallel job (WORLD_SIZE > 1) runs engine.TrainStep, which does not use the
+# launcher, and the collective library's own stream memory operations have never been exercised with this switch.
 _cp_preset = os.environ.get("GPU_STREAMOPS_CP_WAIT")
 _started = _hip_started()
-os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
-CP_WAIT = (_cp_preset == "1") or (_cp_preset is None and not _started)
+_single = os.environ.get("WORLD_SIZE", "1") in ("", "1")
+if _single:
+    os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
+CP_WAIT = (_cp_preset == "1") or (_cp_preset is None and not _started and _single)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MESHVAE_LIB lets a benchmark A/B two builds of the library in one process-per-run session
