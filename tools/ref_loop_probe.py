@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--warm", type=int, default=300)
     a = ap.parse_args()
     import bench
+    if os.environ.get("PROBE_ST_AUTOGRAD") == "1":        # backward on the calling thread (no hop to autograd's device thread)
+        torch.autograd.set_multithreading_enabled(False)
     dev = torch.device("cuda:0")
     B = a.batch
     x = torch.randn(B, 4998, 3, generator=torch.Generator().manual_seed(0)).to(dev)
