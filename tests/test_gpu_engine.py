@@ -913,3 +913,50 @@ def test_async_launcher_reports_a_failed_job_and_leaves_nothing_blocked():
     meshvae_hip.check(L.mvh_launcher_sync(lch))
     torch.cuda.synchronize()
     assert torch.isfinite(outs[2]).all()
+
+
+def test_async_launcher_mixed_usage_equals_the_synchronous_path():
+    """The module path under the asynchronous launcher in the ways a script mixes calls: train steps at changing batch sizes
+    (more sizes than the entry cache holds: an evicted workspace must not be named by a queued job), no_grad evaluations in
+    between, outputs read late, piecewise encoder / sample calls (synchronous, on the caller's stream, same workspace
+    family).  Everything must equal the same sequence with the launcher off, bit for bit."""
+    import meshvae_hip
+    from meshvae_hip.engine import _Batch
+    dev = torch.device("cuda:0")
+    if meshvae_hip.launcher(0) is None:
+        pytest.skip("the asynchronous launcher is not in use on this device / in this environment")
+    g = torch.Generator().manual_seed(21)
+    data = {B: (torch.randn(B, 162, 3, generator=g).to(dev), torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev))
+            for B in (3, 5, 8, 2, 6)}
+
+    def run(use_async):
+        net = _ref_model("tiny", dev, dropout=0.2)
+        net.async_launch = use_async
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+        torch.manual_seed(77)
+        kept, out = [], []
+        for it in range(14):
+            B = (3, 5, 8, 2, 6)[it % 5]
+            x, y = data[B]
+            opt.zero_grad()
+            loss, correct, recon, (kld, rec, z_), y_hat = net(_Batch(x), x.double(), y, m_type="train")
+            kept.append((loss.detach(), recon, z_))                 # read only at the very end
+            loss.backward()
+            opt.step()
+            if it % 4 == 3:
+                net.eval()
+                with torch.no_grad():
+                    ev = net(_Batch(x), x, y, m_type="test")
+                    h = net.encoder(x)
+                    rec2 = net.sample(y, net.z_mean(torch.cat([y.float(), h], -1)))
+                out.append((ev[0].clone(), ev[2].clone(), rec2.clone()))
+                net.train()
+        torch.cuda.synchronize()
+        return ([tuple(t.clone() for t in k) for k in kept], out, {k: v.clone() for k, v in net.state_dict().items()})
+    a, b = run(True), run(False)
+    for ka, kb in zip(a[0], b[0]):
+        assert all(torch.equal(u, v) for u, v in zip(ka, kb))
+    for ea, eb in zip(a[1], b[1]):
+        assert all(torch.equal(u, v) for u, v in zip(ea, eb))
+    assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    meshvae_hip.check(meshvae_hip.lib().mvh_launcher_sync(meshvae_hip.launcher(0)))

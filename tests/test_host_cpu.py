@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CFG_5K, ROOT, TINY_CFG, state_dict_from
+from conftest import CFG_5K, PKG, ROOT, TINY_CFG, state_dict_from
 
 
 def _header_symbols():
@@ -263,3 +263,25 @@ def test_list_meshes_and_obj_round_trip(tmp_path, capsys):
     assert len(index) == 3 and set(labels.values()) == {-1}
     v2, f2 = read_obj(str(tmp_path / "0001_f_0.obj"))
     assert np.array_equal(v2, v) and np.array_equal(f2, f)
+
+
+def test_cp_wait_switch_is_set_only_where_the_launcher_may_run():
+    """meshvae_hip sets GPU_STREAMOPS_CP_WAIT=1 at import (the asynchronous launcher's value waits on the command processor
+    instead of a spinning shader) -- in single-process jobs only, never over a caller's own setting, and it reports through
+    meshvae_hip.CP_WAIT whether the launcher may be used.  Child processes: the decision is taken at import time."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import meshvae_hip; "
+            "print(os.environ.get('GPU_STREAMOPS_CP_WAIT'), meshvae_hip.CP_WAIT)" % PKG)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("GPU_STREAMOPS_CP_WAIT", "WORLD_SIZE")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-500:]
+        return out.stdout.split()
+    assert run() == ["1", "True"]                                   # nothing set: switched on, launcher allowed
+    assert run(GPU_STREAMOPS_CP_WAIT="0") == ["0", "False"]         # the caller's choice stands
+    assert run(GPU_STREAMOPS_CP_WAIT="1") == ["1", "True"]
+    assert run(WORLD_SIZE="8") == ["None", "False"]                 # a rank of a data-parallel job: untouched
+    assert run(WORLD_SIZE="1") == ["1", "True"]
