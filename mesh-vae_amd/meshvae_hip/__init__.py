@@ -168,6 +168,7 @@ def check(rc):
 
 
 _launchers = {}
+_launcher_pid = None
 
 
 def launcher(device_index):
@@ -184,14 +185,18 @@ def launcher(device_index):
                 h = ctypes.c_void_p()
                 check(lib().mvh_launcher_create(ctypes.byref(h)))
                 handle = h
-                if not _launchers:
+                global _launcher_pid
+                if _launcher_pid is None:
                     import atexit
+                    _launcher_pid = os.getpid()
                     atexit.register(_destroy_launchers)
     _launchers[device_index] = handle
     return handle
 
 
 def _destroy_launchers():
+    if os.getpid() != _launcher_pid:        # a forked child (a DataLoader worker) owns neither the thread nor the stream
+        return
     for k, h in list(_launchers.items()):
         if h is not None:
             lib().mvh_launcher_destroy(h)

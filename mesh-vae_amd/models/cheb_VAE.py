@@ -222,11 +222,12 @@ class cheb_VAE(torch.nn.Module):
         (:316) -- but moved with an asynchronous copy from a small ring of pinned buffers: the reference's pageable
         `.to(device)` makes the host wait for everything queued on the stream, once per step."""
         rings = self.__dict__.setdefault("_eps_rings", {})
-        ring = rings.get(B)
+        key = (B, dev.index)
+        ring = rings.get(key)
         if ring is None:
             if len(rings) >= 4:
                 rings.pop(next(iter(rings)))
-            ring = rings[B] = {"i": 0, "slots": [(torch.empty(B, self.z).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
+            ring = rings[key] = {"i": 0, "slots": [(torch.empty(B, self.z).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
         buf, ev = ring["slots"][ring["i"]]
         ring["i"] = (ring["i"] + 1) % len(ring["slots"])
         ev.synchronize()                                   # the copy that read this buffer four draws ago
