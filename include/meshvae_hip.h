@@ -73,7 +73,41 @@ typedef struct mvh_csr {
    * exactly one entry of value 1 and no column repeats; sel_inv[c] = the row that selects column
    * c, or -1.  Lets the step engine fold the pooling into the neighbouring convolutions. */
   const int32_t* sel_inv; /* [n_cols] device */
+  /* Optional vertex-patch plan of a level's Laplacian (NULL = none): lets the 16 -> 16 convolutions of a 2 049 ..
+   * 5 119-vertex level run as (mesh, vertex patch) workgroups with all channels on chip and the K Cin x Cout
+   * contraction on v_mfma_f32_16x16x4_f32 (csrc/cheb_patch.hip) instead of (mesh, 4-channel slab) workgroups. */
+  const struct mvh_patch_plan* patch;
 } mvh_csr_t;
+
+/* Vertex-patch plan (built on the host by meshvae_hip/patches.py; every array on the device).  A level's vertices are
+ * partitioned into n_patches EXCLUSIVE sets; patch p additionally carries the rows a fused pooling needs (its CORE) and
+ * n_rings breadth-first rings around the core -- what the recurrence T_k = 2 L T_{k-1} - T_{k-2} (nn/conv.py:568-572)
+ * of a layer with K - 1 <= n_rings needs to be exact on the core.  Local numbering of a patch: exclusive vertices,
+ * rest of the core, ring 1, ..., ring n_rings; padded to whole 16-vertex tiles.
+ *   poff[p]            first local slot of patch p in pinfo / ell (multiples of 16); poff[n_patches] = total slots
+ *   cnt[p][0]          exclusive vertices;  cnt[p][1 + r] = local vertices of ring <= r (r = 0: the core)
+ *   pinfo[slot]        global vertex id | degree << 16 | ring << 24 | exclusive << 28  (pad slots: ring 15)
+ *   ell[slot][4]       8 neighbours as LOCAL ids x 5 (LDS row stride in 16-byte units), two uint16 per word;
+ *                      pad = 5 x (slots of the patch) = the zero row the kernels keep behind the last tile
+ *   pooling (n_pool_rows > 0: rows of a pooling operator's transpose, nn/pool.py:17-20 backward, e.g. U^T):
+ *   prow_off[p]        first assigned coarse row of patch p in prow_gid; rows prow_off[p] .. prow_off[p+1]
+ *   prow_gid[i]        coarse row id;  prow_ptr[prow_off[p] + p + i .. + 1] = its entries in pcol / pval
+ *   pcol / pval        LOCAL column (a core vertex of the patch) and value, in the operator's own entry order */
+typedef struct mvh_patch_plan {
+  int32_t n_patches, n_rings, n_vertices;
+  int32_t max_rows, max_core, max_excl;   /* largest patch: padded slots, core vertices, exclusive vertices */
+  int32_t n_pool_rows, reserved;
+  const int32_t* poff;
+  const int32_t* cnt;      /* [n_patches][n_rings + 2] */
+  const uint32_t* pinfo;
+  const uint32_t* ell;
+  const int32_t* prow_off;
+  const int32_t* prow_gid;
+  const int32_t* prow_ptr;
+  const int32_t* pcol;
+  const float* pval;
+  const int32_t* pool_rowptr; /* rowptr of the pooling operator the rows above were taken from (identity check), or NULL */
+} mvh_patch_plan_t;
 
 /* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh
  * Laplacian of ChebConv_batch.norm (nn/conv.py:541-555) on unit edge weights. */
@@ -88,7 +122,7 @@ typedef struct mvh_csr {
  * any other call (the Python binding does, meshvae_hip/__init__.py).  History: 100 = round 1; 300 = `storage`
  * inserted into mvh_vae_desc_t, skip_lo / skip_hi appended to mvh_adam_step / mvh_adam_step_counted (round 2,
  * shipped unversioned), version check introduced (round 3). */
-#define MVH_ABI_VERSION 310
+#define MVH_ABI_VERSION 320
 int mvh_version(void);
 const char* mvh_last_error(void);
 /* Device properties of the current HIP device (arch string e.g. "gfx950"). */

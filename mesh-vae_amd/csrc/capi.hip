@@ -51,7 +51,9 @@ static const DebugKey kDebugKeys[] = {
     {"no_final_fuse", &DebugCfg::no_final_fuse}, {"fork_small", &DebugCfg::fork_small},
     {"l0_lane", &DebugCfg::l0_lane},             {"l0_lane_any", &DebugCfg::l0_lane_any},
     {"l0_lane_bf", &DebugCfg::l0_lane_bf},       {"l0_hold", &DebugCfg::l0_hold},
-    {"enc_dense", &DebugCfg::enc_dense},
+    {"enc_dense", &DebugCfg::enc_dense},         {"no_patch", &DebugCfg::no_patch},
+    {"patch_flush_first", &DebugCfg::patch_flush_first}, {"no_patch_bwd", &DebugCfg::no_patch_bwd},
+    {"patch_fwd_threads", &DebugCfg::patch_fwd_threads}, {"patch_bwd_threads", &DebugCfg::patch_bwd_threads},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

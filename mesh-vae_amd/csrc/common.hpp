@@ -129,6 +129,10 @@ struct DebugCfg {
   int sched_hold = 0;      // base-4 digit k: forks of the chain item k lets pass before it is launched
   int skip_xty = 0;        // TIMING ONLY, results invalid: the final layer's S = x^T dout pass (k_xty_small) is not launched
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
+  int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
+  int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
+  int patch_flush_first = 0;   // 1: the step forks the weight-gradient items queued so far BEFORE a patch backward launch
+  int patch_fwd_threads = 0, patch_bwd_threads = 0;   // block size of the patch kernels (512 / 768 / 1024; 0 = built-in)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
@@ -290,6 +294,14 @@ int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* la
                        float* dx_pooled = nullptr           /* decoder's upsampling backward); falls back to dx + spmm */,
                        const ConvIO& io = ConvIO());
 constexpr size_t kLdsWpackBytes = 64 * 1024;
+// vertex-patch kernels of a level's 16 -> 16 layers (cheb_patch.hip; the plan hangs off the Laplacian: mvh_csr_t::patch)
+bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
+size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K);
+int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
+                     uint8_t* bits, int B, int N, int K, int act);
+int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
+                     const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
+                     float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K);
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,

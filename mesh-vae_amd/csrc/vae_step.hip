@@ -761,6 +761,39 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                              nullptr, nullptr, nullptr, 0, nullptr, &d->up_t[lvl], dst, io));
       continue;
     }
+    // A level with a vertex-patch plan (cheb_patch.hip; the 5k level's 16 -> 16 stage): dX, its U^T pooling and the dW / db
+    // partial tiles come out of ONE launch on the main chain -- nothing of this stage on the weight-gradient lanes (the
+    // slab form: a 43 us dX launch on the chain + two 71 us half-batch dW launches that hold 128 CUs each on the dense lane)
+    if (!bf && !dx_first && !dbg().no_patch_bwd && BITS(p.decBits[i]) && red.n < (int)(sizeof(red.e) / sizeof(red.e[0])) &&
+        patch_eligible(&d->lap_t[lvl], p.Nn[lvl], cin, cout, d->K[i]) &&
+        p.dwPartBytesDec[i] >= patch_part_bytes(&d->lap_t[lvl], B, d->K[i])) {
+      if (dbg().patch_flush_first) TRY(flush_dw(false));   // (queued items of the final layer start beside this launch, not behind it)
+      bool dfr = false;
+      TRY(cheb_conv_bwd_impl(main, &d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
+                             nullptr, F(p.g_decU[i]), G[ix.decW(i)], G[ix.decB(i)], B, p.Nn[lvl], cin, cout, d->K[i],
+                             MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_b[i]), nullptr, nullptr, BITS(p.decBits[i]),
+                             nullptr, &red.e[red.n], F(p.dwPartDec[i]), p.dwPartBytesDec[i], &dfr, &d->up_t[lvl], dst, io));
+      MVH_REQUIRE(dfr, "vae_backward: the patch kernel did not defer its weight-gradient reduction");
+      ++red.n;
+      if (i == n - 1 && use_tstack) {
+        if (side->tstack_pending && side->tstack_x == x && side->tstack_ws == ws && side->tstack_stream == sstream) {
+          ev_tstack = side->tstack_done;      // built ahead of the forward (mvh_vae_backward_prefetch)
+        } else {
+          TRY(flush_dw(false));
+          MVH_HIP(hipEventRecord(side->ev[ev], main));
+          MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
+          ev = (ev + 1) % side->n_ev;
+          TRY(launch_tstack(sstream, &d->lap[0], &d->down[0], x, F(p.tstack), B, p.Nn[0], p.f[0], d->K[0]));
+          if (sstream != main) {
+            MVH_HIP(hipEventRecord(side->ev[ev], sstream));
+            ev_tstack = side->ev[ev];
+            ev = (ev + 1) % side->n_ev;
+          }
+        }
+        side->tstack_pending = false;
+      }
+      continue;
+    }
     if (dx_first) TRY(dx_this());
     TRY(conv_dw_side(&d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,

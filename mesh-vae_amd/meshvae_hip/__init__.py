@@ -57,7 +57,18 @@ class CsrStruct(ctypes.Structure):
                 ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
                 ("rowinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p), ("ell_pairs", ctypes.c_int32),
                 ("max_row_nnz", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("n_active", ctypes.c_int32), ("sub", ctypes.c_void_p), ("sel_inv", ctypes.c_void_p)]
+                ("n_active", ctypes.c_int32), ("sub", ctypes.c_void_p), ("sel_inv", ctypes.c_void_p),
+                ("patch", ctypes.c_void_p)]
+
+
+class PatchPlanStruct(ctypes.Structure):
+    """mvh_patch_plan_t (built by meshvae_hip/patches.py)"""
+    _fields_ = [("n_patches", ctypes.c_int32), ("n_rings", ctypes.c_int32), ("n_vertices", ctypes.c_int32),
+                ("max_rows", ctypes.c_int32), ("max_core", ctypes.c_int32), ("max_excl", ctypes.c_int32),
+                ("n_pool_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("poff", ctypes.c_void_p), ("cnt", ctypes.c_void_p), ("pinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p),
+                ("prow_off", ctypes.c_void_p), ("prow_gid", ctypes.c_void_p), ("prow_ptr", ctypes.c_void_p),
+                ("pcol", ctypes.c_void_p), ("pval", ctypes.c_void_p), ("pool_rowptr", ctypes.c_void_p)]
 
 
 VAE_MAX_LAYERS = 8
@@ -77,7 +88,7 @@ class VaeDesc(ctypes.Structure):
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
 STORAGE_F32, STORAGE_BF16 = 0, 1
-ABI_VERSION = 310   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
+ABI_VERSION = 320   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 

@@ -578,6 +578,17 @@ class NativeStep:
             d.down[i], d.down_t[i] = net._down[i].fwd.struct, net._down[i].bwd.struct
             d.up[i], d.up_t[i] = net._up[i].fwd.struct, net._up[i].bwd.struct
         d.lap[n], d.lap_t[n] = net._lap_final.fwd.struct, net._lap_final.bwd.struct
+        # vertex-patch plans (csrc/cheb_patch.hip): the 16 -> 16 decoder stage of a 2 049 .. 5 119-vertex level runs as
+        # (mesh, vertex patch) workgroups; the plan hangs off the desc's COPY of the level's Laplacian (fp32 storage)
+        self._patch_keep = []
+        from . import topology
+        for i in range(n):
+            j = n - 1 - i                                    # decoder stage of level i: filters[i + 2] -> filters[i + 1]
+            if storage != "bf16" and net.filters[i + 1] == 16 and net.filters[i + 2] == 16:
+                got = topology.patch_plan(net._lap[i], int(net.K[j]) - 1, net._up[i])
+                if got is not None:
+                    self._patch_keep.append(got)
+                    d.lap[i].patch = d.lap_t[i].patch = ctypes.addressof(got[0])
         self.desc = d
         L = lib()
         self.params = [p for _, p in net.named_parameters()]

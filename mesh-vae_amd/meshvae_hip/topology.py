@@ -209,8 +209,41 @@ def laplacian(edge_index, norm, num_nodes):
             sub = Operator(edge_index[1], edge_index[0], norm, na, na, norm.device)
             op.fwd.attach_sub(sub.fwd)
             op.bwd.attach_sub(sub.bwd)
+        # a level the vertex-patch kernels take (csrc/cheb_patch.hip): 16 -> 16 layers of up to K = 6 run as (mesh, patch)
+        # workgroups; plain plan (no fused pooling) for the module-level calls -- the step engine attaches its own
+        got = patch_plan(op, 5)
+        if got is not None:
+            import ctypes
+            op.fwd.struct.patch = op.bwd.struct.patch = ctypes.addressof(got[0])
         hit = _cache[k] = (op, edge_index, norm)   # keep the tensors alive: data_ptr is the key
     return hit[0]
+
+
+def patch_plan(lap_op, n_rings, up_op=None):
+    """Vertex-patch plan (meshvae_hip/patches.py, csrc/cheb_patch.hip) of a level's Laplacian, uploaded:
+    -> (PatchPlanStruct, keep-alive) or None when the level is not one the patch kernels take (2 049 .. 5 119 vertices,
+    normalised symmetric Laplacian, at most 8 neighbours, a cut whose largest patch fits the LDS).  up_op: the level's
+    un-pooling Operator (coarse -> this level); its transpose's rows are then formed inside the backward kernel."""
+    import ctypes
+    from . import patches
+    csr = lap_op.fwd
+    need = CSR_NORMALIZED_LAPLACIAN | CSR_SYMMETRIC
+    if (csr.flags & need) != need or not (2048 < csr.n_rows + 1 <= 5120) or csr.max_row_nnz > patches.MAX_DEG or n_rings < 0:
+        return None
+    cache = lap_op.__dict__.setdefault("_patch_plans", {})
+    key = (int(n_rings), None if up_op is None else id(up_op))
+    if key not in cache:
+        rowptr = csr.rowptr.cpu().numpy().astype(np.int64)
+        rows = np.repeat(np.arange(csr.n_rows), rowptr[1:] - rowptr[:-1])
+        cols = csr.col.cpu().numpy().astype(np.int64)
+        pool_t, pool_rowptr = None, None
+        if up_op is not None and up_op.bwd.n_cols == csr.n_rows:
+            t = up_op.bwd                                     # U^T: rows = coarse vertices, columns = this level
+            pool_t = (t.rowptr.cpu().numpy().astype(np.int64), t.col.cpu().numpy().astype(np.int64), t.val.cpu().numpy())
+            pool_rowptr = t.rowptr
+        plan = patches.build_plan(csr.n_rows, rows, cols, int(n_rings), pool_t)
+        cache[key] = None if plan is None else plan.device(csr.rowptr.device, pool_rowptr) + (plan, up_op)
+    return cache[key]
 
 
 def pool_operator(pool_mat):

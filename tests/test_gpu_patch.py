@@ -1,0 +1,164 @@
+"""GPU: the vertex-patch ChebConv kernels (csrc/cheb_patch.hip, plans from meshvae_hip/patches.py) against the CPU oracle
+and against the slab kernels they replace.
+
+A level of 2 049 .. 5 119 vertices whose graph cuts into patches that fit a CU (the 5k hip-bone template: two bones, four
+patches; a 5k torus: five) runs its 16 -> 16 layers as (mesh, vertex patch) workgroups with the K Cin x Cout contraction
+on v_mfma_f32_16x16x4_f32.  Bars: forward within 1e-4 absolute of the oracle (nn/conv.py:557-577's contract), gradients
+within 1e-4 relative; forward and dX do not depend on the cut (every vertex sums its neighbours in adjacency order), so the
+plan with fused pooling rows and the plain plan must agree BITWISE on them."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(npz):
+    ei = torch.from_numpy(np.stack([npz["A0_row"], npz["A0_col"]]).astype(np.int64))
+    return ei, int(npz["num_nodes"][0])
+
+
+def _conv_case(ei_cpu, N, K, relu, B=3, seed=0, no_patch=False):
+    import meshvae_hip
+    from nn.conv import ChebConv_batch
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, 16, generator=g)
+    w = torch.randn(K, 16, 16, generator=g) * 0.1
+    b = torch.randn(16, generator=g) * 0.1
+    gy = torch.randn(B, N, 16, generator=g)
+    ei, nrm = ChebConv_batch.norm(ei_cpu.to(dev), N)
+    conv = ChebConv_batch(16, 16, K).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+    xd = x.to(dev).requires_grad_(True)
+    with meshvae_hip.debug_switch("no_patch", 1 if no_patch else 0):
+        y = conv(xd, ei, nrm, relu=relu)
+        y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    return (x, w, b, gy), (y.detach().cpu(), xd.grad.cpu(), conv.weight.grad.cpu(), conv.bias.grad.cpu())
+
+
+def _oracle(ei_cpu, N, x, w, b, gy, relu):
+    from oracle import cheb_oracle as O
+    eio, nrmo = O.cheb_norm(ei_cpu, N)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yo = O.cheb_conv(xo, eio, nrmo, wo, bo)
+    if relu:
+        yo = torch.relu(yo)
+    yo.backward(gy)
+    return yo.detach(), xo.grad, wo.grad, bo.grad
+
+
+def _has_plan(ei_cpu, N):
+    from meshvae_hip import topology
+    from nn.conv import ChebConv_batch
+    dev = torch.device("cuda:0")
+    ei, nrm = ChebConv_batch.norm(ei_cpu.to(dev), N)
+    op = topology.laplacian(ei, nrm, N)
+    return bool(op.fwd.struct.patch), op
+
+
+@pytest.mark.parametrize("fixture,K,relu,B", [("topology_5k.npz", 6, True, 3), ("topology_5k.npz", 6, False, 9),
+                                              ("topology_5k.npz", 3, True, 2), ("topology_5k.npz", 1, True, 2),
+                                              ("hier_torus5k.npz", 6, True, 3), ("hier_torus5k.npz", 5, False, 1)])
+def test_patch_conv_matches_oracle_and_slab_kernels(fixture, K, relu, B):
+    from conftest import load_golden
+    ei_cpu, N = _edges(load_golden(fixture))
+    has, _ = _has_plan(ei_cpu, N)
+    assert has, "the level must carry a patch plan (meshvae_hip/patches.py)"
+    ins, got = _conv_case(ei_cpu, N, K, relu, B=B, seed=K + B)
+    ref = _oracle(ei_cpu, N, *ins, relu)
+    _, slab = _conv_case(ei_cpu, N, K, relu, B=B, seed=K + B, no_patch=True)
+    y, dx, dw, db = got
+    torch.testing.assert_close(y, ref[0], rtol=0, atol=1e-4)
+    if relu:
+        assert torch.equal(y > 0, ref[0] > 0)
+    torch.testing.assert_close(dx, ref[1], rtol=1e-4, atol=1e-4)
+    sw, sb = float(ref[2].abs().max()), float(ref[3].abs().max())
+    torch.testing.assert_close(dw, ref[2], rtol=1e-4, atol=1e-5 * sw + 1e-5)
+    torch.testing.assert_close(db, ref[3], rtol=1e-4, atol=1e-5 * sb + 1e-5)
+    # ... and the kernels it replaces (fp32 reassociation only)
+    torch.testing.assert_close(y, slab[0], rtol=0, atol=2e-5)
+    torch.testing.assert_close(dx, slab[1], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dw, slab[2], rtol=1e-4, atol=1e-5 * sw + 1e-5)
+
+
+def test_patch_kernels_really_ran():
+    """The switch `no_patch` changes which kernels run: with the same inputs the two paths agree to rounding but not
+    bitwise (different summation trees) -- a silent fallback to the slab kernels would make them identical."""
+    from conftest import load_golden
+    ei_cpu, N = _edges(load_golden("topology_5k.npz"))
+    _, a = _conv_case(ei_cpu, N, 6, True, B=2, seed=5)
+    _, b = _conv_case(ei_cpu, N, 6, True, B=2, seed=5, no_patch=True)
+    assert not torch.equal(a[0], b[0])
+    torch.testing.assert_close(a[0], b[0], rtol=0, atol=2e-5)
+
+
+def test_patch_block_sizes_agree_bitwise_on_forward_and_dx():
+    """512 / 768 / 1024-thread workgroups cut the tiles differently over the waves; a vertex's arithmetic is the same."""
+    import meshvae_hip
+    from conftest import load_golden
+    ei_cpu, N = _edges(load_golden("topology_5k.npz"))
+    outs = []
+    for th in (512, 768, 1024):
+        with meshvae_hip.debug_switch("patch_fwd_threads", th), meshvae_hip.debug_switch("patch_bwd_threads", th):
+            _, got = _conv_case(ei_cpu, N, 6, True, B=2, seed=11)
+        outs.append(got)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        sw = float(outs[0][2].abs().max())
+        torch.testing.assert_close(o[2], outs[0][2], rtol=1e-4, atol=1e-5 * sw + 1e-5)   # (other wave / group order)
+        torch.testing.assert_close(o[3], outs[0][3], rtol=1e-5, atol=1e-6)
+
+
+def test_plan_with_pooling_rows_matches_spmm_of_plain_dx():
+    """The step engine's form: dX pooled by U^T inside the kernel (plan built with the level's un-pooling operator)
+    against pool_bwd of the plain kernel's dX, and both plans' dW."""
+    import meshvae_hip
+    from conftest import load_golden
+    from meshvae_hip import lib, check, topology
+    from nn.conv import ChebConv_batch
+    npz = load_golden("topology_5k.npz")
+    ei_cpu, N = _edges(npz)
+    dev = torch.device("cuda:0")
+    ei, nrm = ChebConv_batch.norm(ei_cpu.to(dev), N)
+    lap = topology.laplacian(ei, nrm, N)
+    U = torch.sparse_coo_tensor(torch.from_numpy(np.stack([npz["U0_row"], npz["U0_col"]]).astype(np.int64)),
+                                torch.from_numpy(npz["U0_val"]), tuple(int(v) for v in npz["U0_shape"])).to(dev)
+    up = topology.pool_operator(U)
+    got = topology.patch_plan(lap, 5, up)
+    assert got is not None and got[0].n_pool_rows == up.n_in
+    B, K = 5, 6
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, N, 16, generator=g).to(dev)
+    w = (torch.randn(K, 16, 16, generator=g) * 0.1).to(dev)
+    gy = torch.randn(B, N, 16, generator=g).to(dev)
+    signs = (torch.rand(B, N, 4, generator=g) * 16).to(torch.uint8).to(dev)
+    L = lib()
+    ws_bytes = L.mvh_cheb_conv_bwd_ws_bytes(B, N, 16, 16, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(patch_ptr):
+        fwd, bwd = meshvae_hip.CsrStruct.from_buffer_copy(lap.fwd.struct), meshvae_hip.CsrStruct.from_buffer_copy(lap.bwd.struct)
+        fwd.patch = bwd.patch = patch_ptr
+        dx, dw, db = torch.empty(B, N, 16, device=dev), torch.empty(K, 16, 16, device=dev), torch.empty(16, device=dev)
+        check(L.mvh_cheb_conv_bwd_signs(st, ctypes.byref(fwd), ctypes.byref(bwd), x.data_ptr(), w.data_ptr(), None,
+                                        signs.data_ptr(), gy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                        B, N, 16, 16, K, ws.data_ptr(), ws_bytes))
+        torch.cuda.synchronize()
+        return dx, dw, db
+    dx_a, dw_a, db_a = run(lap.fwd.struct.patch)                  # plain plan
+    dx_b, dw_b, db_b = run(ctypes.addressof(got[0]))              # plan with pooling rows (dx not pooled by this entry)
+    assert torch.equal(dx_a, dx_b)
+    torch.testing.assert_close(dw_a, dw_b, rtol=1e-4, atol=1e-5 * float(dw_a.abs().max()) + 1e-5)
+    torch.testing.assert_close(db_a, db_b, rtol=1e-5, atol=1e-6)
+    with meshvae_hip.debug_switch("no_patch", 1):
+        dx_c, dw_c, db_c = run(None)
+    torch.testing.assert_close(dx_a, dx_c, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dw_a, dw_c, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db_a, db_c, rtol=1e-4, atol=1e-4)

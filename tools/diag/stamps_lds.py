@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=16); ap.add_argument("--cout", type=int, default=16)
 ap.add_argument("--k", type=int, default=6); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--level", type=int, default=0); ap.add_argument("--bwd", action="store_true"); ap.add_argument("--dw", action="store_true")
+ap.add_argument("--patch", action="store_true", help="the vertex-patch kernels (cheb_patch.hip): --bwd = dX + dW in one launch")
 args = ap.parse_args()
 from meshvae_hip import check, lib, topology
 from meshvae_hip.functional import workspace
@@ -32,7 +33,7 @@ wsb = max(L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), L.mvh_cheb_conv_bwd_ws_b
 ws = workspace(wsb, dev)
 st = torch.cuda.current_stream(dev).cuda_stream
 dW, db = torch.empty_like(W), torch.empty_like(bias)
-rd = L.mvh_debug_read_stamps_dw if args.dw else L.mvh_debug_read_stamps_lds
+rd = L.mvh_debug_read_stamps_patch if args.patch else (L.mvh_debug_read_stamps_dw if args.dw else L.mvh_debug_read_stamps_lds)
 rd.restype, rd.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
 
 def run():
@@ -41,7 +42,7 @@ def run():
                                         dout.data_ptr(), None, dW.data_ptr(), db.data_ptr(), B, N, Cin, Cout, K, ws.data_ptr(), wsb))
     elif args.bwd:
         check(L.mvh_cheb_conv_bwd_signs(st, op.fwd.ref, op.bwd.ref, x.data_ptr(), W.data_ptr(), out.data_ptr(), signs.data_ptr(),
-                                        dout.data_ptr(), dx.data_ptr(), None, None, B, N, Cin, Cout, K, ws.data_ptr(), wsb))
+                                        dout.data_ptr(), dx.data_ptr(), dW.data_ptr() if args.patch else None, db.data_ptr() if args.patch else None, B, N, Cin, Cout, K, ws.data_ptr(), wsb))
     else:
         check(L.mvh_cheb_conv_fwd_signs(st, op.fwd.ref, x.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), signs.data_ptr(),
                                         B, N, Cin, Cout, K, ws.data_ptr(), wsb))
