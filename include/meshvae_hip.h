@@ -96,7 +96,7 @@ typedef struct mvh_csr {
 typedef struct mvh_patch_plan {
   int32_t n_patches, n_rings, n_vertices;
   int32_t max_rows, max_core, max_excl;   /* largest patch: padded slots, core vertices, exclusive vertices */
-  int32_t n_pool_rows, reserved;
+  int32_t n_pool_rows, min_core;          /* min_core: core vertices of the smallest patch */
   const int32_t* poff;
   const int32_t* cnt;      /* [n_patches][n_rings + 2] */
   const uint32_t* pinfo;

@@ -112,7 +112,9 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
   const int nt_out = (n_excl + 15) >> 4;
   const int nt0 = (c[1 + min(a.R, K - 1)] + 15) >> 4;     // tiles whose u_0 somebody needs
 
-  float4 nw[SLOTS], pv[SLOTS];
+  // st[s]: between two orders u_{k-2} of the slot's own row quad; inside order k, from its gather on, u_k (the swap
+  // behind the barrier trades it for the row's u_{k-1}, which the next order subtracts)
+  float4 st[SLOTS];
   v4f acc[ASLOTS];
   float wa[4];
   auto load_w = [&](int k) {
@@ -122,29 +124,23 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
   load_w(0);
   const float* xb = p_x + (long long)mesh * a.N * 16;
 #pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int t = s * NW + w;
-    pv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    nw[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < nt_all) {
-      const int v = 16 * t + vi;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < nt0) {
-        const uint32_t info = p_pinfo[o + v];
-        const float deg = (float)((info >> 16) & 255u);
-        const bool valid = (info >> 24 & 15u) != 15u;
-        const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-        const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)(info & 0xffffu) * 16 + 4 * q);
-        r = make_float4(xv.x * sc, xv.y * sc, xv.z * sc, xv.w * sc);
-      }
-      *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
-      nw[s] = r;
+    st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int v = 16 * t + vi;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < nt0) {
+      const uint32_t info = p_pinfo[o + v];
+      const float deg = (float)((info >> 16) & 255u);
+      const bool valid = (info >> 24 & 15u) != 15u;
+      const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+      const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)(info & 0xffffu) * 16 + 4 * q);
+      r = make_float4(xv.x * sc, xv.y * sc, xv.z * sc, xv.w * sc);
     }
-  }
-#pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) {
-    acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
-    mfma4(acc[s], wa, nw[s]);
+    if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
+    if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, r);     // (outside every run-time branch)
   }
   MVH_STAMPX(1);
   __syncthreads();
@@ -162,9 +158,9 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
         const uint4 id = *reinterpret_cast<const uint4*>(smem + (size_t)v * kRowB + 64);
         const float cc = coefv[v] * sc;
         const float4 g = gather8(lane_base, id);
-        nw[s] = make_float4(fmaf(cc, g.x, -pv[s].x), fmaf(cc, g.y, -pv[s].y), fmaf(cc, g.z, -pv[s].z),
-                            fmaf(cc, g.w, -pv[s].w));
-        if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, nw[s]);   // (tiles past the last output tile: unused columns)
+        st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
+                            fmaf(cc, g.w, -st[s].w));
+        if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);   // (tiles past the last output tile: unused columns)
       }
       __builtin_amdgcn_sched_barrier(0);   // one slot's gathers in flight at a time (registers)
     }
@@ -177,8 +173,9 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
       const int t = s * NW + w;
       if (t < ntk) {
         float4* own = reinterpret_cast<float4*>(u + (size_t)(16 * t + vi) * kRowF + 4 * q);
-        pv[s] = *own;
-        *own = nw[s];
+        const float4 old = *own;
+        *own = st[s];
+        st[s] = old;
       }
     }
     __syncthreads();
@@ -210,9 +207,13 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
-// GSLOTS >= 4-vertex groups of the largest exclusive set / waves.
-// XREG: the weight gradient's A operand (the patch's own x rows) stays in registers; else it is re-read per order (L2).
-template <int THREADS, int SLOTS, int ASLOTS, int GSLOTS, bool XREG>
+// GSLOTS >= 4-vertex groups of the largest exclusive set / waves.  The weight gradient of order k - 1 rides in order k's
+// slot loop: slot s issues the x loads of its chunk of the wave's groups, gathers, and then feeds the matrix pipe with
+// that chunk (A = D^1/2 x from L2, B = u_{k-1} rows from LDS), so the loads' latency sits under a slot's gathers and the
+// matrix instructions of both gradients are spread between the LDS bursts.
+// SU: the first SU tile slots of every wave are core tiles in every patch (needed at every order): no run-time test
+// around them, i.e. no control flow between the x prefetch and its use (the waitcnt pass then counts exactly).
+template <int THREADS, int SLOTS, int ASLOTS, int GSLOTS, int SU>
 __global__ void __launch_bounds__(THREADS)
 k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbits, const float* __restrict__ p_g3,
             const float* __restrict__ p_w3, const float* __restrict__ p_x, const float* __restrict__ p_W,
@@ -222,6 +223,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
             const int32_t* __restrict__ p_prow_ptr, const int32_t* __restrict__ p_pcol, const float* __restrict__ p_pval,
             PatchDims a) {
   constexpr int NW = THREADS / 64;
+  constexpr int CH = (GSLOTS + SLOTS - 1) / SLOTS;     // groups of a wave per slot
   extern __shared__ __align__(16) unsigned char smem[];
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int mesh = (jj / a.P) * 8 + xcd, pt = jj % a.P;
@@ -231,30 +233,31 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   const int o = p_poff[pt], rows16 = p_poff[pt + 1] - o;
   const int* __restrict__ c = p_cnt + pt * (a.R + 2);
   const int K = a.K;
+  const int n_excl = c[0], n_core = c[1];
+  const int nt_all = rows16 >> 4;
+  const int nt_out = a.has_dx ? (n_core + 15) >> 4 : 0;
+  const int nt0 = (c[1 + min(a.R, K - 1)] + 15) >> 4;
+  const int ng = a.has_dw ? (n_excl + 3) >> 2 : 0;          // 4-vertex groups of the weight gradient
   float* u = reinterpret_cast<float*>(smem);
   float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);   // -2 / deg per local vertex
-  float* wpart = coefv + rows16;                   // [NW][256] the waves' dW_k tiles of one order, [NW][16] their db sums
+  float* wpart = coefv + rows16;                   // [NW][256] the waves' dW tiles of one order, [NW][16] their db sums
   float* wdb = wpart + NW * 256;
+  uint32_t* xinfo = reinterpret_cast<uint32_t*>(wdb + NW * 16);   // [4 NW SLOTS CH] global id | max(deg, 1) << 16; 0 off the exclusive set
   const unsigned char* lane_base = smem + 16 * q;
   MVH_STAMPX(0);
 
   for (int i = tid; i < rows16; i += THREADS) {
     *reinterpret_cast<uint4*>(smem + (size_t)i * kRowB + 64) = reinterpret_cast<const uint4*>(p_ell)[o + i];
     const uint32_t info = p_pinfo[o + i];
-    const float deg = (float)((info >> 16) & 255u);
-    coefv[i] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+    const uint32_t dg = (info >> 16) & 255u;
+    coefv[i] = dg > 0u ? -2.0f * __builtin_amdgcn_rcpf((float)dg) : 0.f;
+    if (i < 4 * NW * SLOTS * CH) xinfo[i] = ((info >> 28) & 1u) && a.has_dw ? ((info & 0xffffu) | (max(dg, 1u) << 16)) : 0u;
   }
+  for (int i = rows16 + tid; i < 4 * NW * SLOTS * CH; i += THREADS) xinfo[i] = 0u;   // (every group slot of every wave exists)
   if (tid < kRowF / 4) reinterpret_cast<float4*>(u + (size_t)rows16 * kRowF)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const int n_excl = c[0], n_core = c[1];
-  const int nt_all = rows16 >> 4;
-  const int nt_out = a.has_dx ? (n_core + 15) >> 4 : 0;
-  const int nt0 = (c[1 + min(a.R, K - 1)] + 15) >> 4;
-  const int ng = a.has_dw ? (n_excl + 3) >> 2 : 0;          // 4-vertex groups of the weight gradient
-
-  float4 nw[SLOTS], pv[SLOTS];
+  float4 st[SLOTS];     // (see k_patch_fwd)
   v4f acc[ASLOTS];
-  float xa[XREG ? GSLOTS : 1];
   float wa[4];
   auto load_w = [&](int k) {   // A = W_k^T: [c_in = vi][c_out = 4 q + s]
     const float4 t = *reinterpret_cast<const float4*>(p_W + k * 256 + vi * 16 + 4 * q);
@@ -264,6 +267,8 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   const long long mrow = (long long)mesh * a.N;
   const int wg = mesh * a.P + pt;          // this workgroup's partial tile (one per slab)
   const int tile = (K + 1) * 64;
+#pragma unroll
+  for (int s = 0; s < ASLOTS; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
   {
     // lazy rows: this lane's four columns of W3 [16][3]
     float w3r[4][3];
@@ -277,41 +282,38 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int t = s * NW + w;
-      pv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-      nw[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < nt_all) {
-        const int v = 16 * t + vi;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < nt0) {
-          const uint32_t info = p_pinfo[o + v];
-          const float deg = (float)((info >> 16) & 255u);
-          const bool valid = (info >> 24 & 15u) != 15u;
-          const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-          const int gid = (int)(info & 0xffffu);
-          float4 dv;
-          if (a.src3_n >= 0 && gid >= a.src3_n) {
-            const float* gr = p_g3 + (mrow + gid) * 3;
-            const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
-            dv.x = fmaf(g2, w3r[0][2], fmaf(g1, w3r[0][1], g0 * w3r[0][0]));
-            dv.y = fmaf(g2, w3r[1][2], fmaf(g1, w3r[1][1], g0 * w3r[1][0]));
-            dv.z = fmaf(g2, w3r[2][2], fmaf(g1, w3r[2][1], g0 * w3r[2][0]));
-            dv.w = fmaf(g2, w3r[3][2], fmaf(g1, w3r[3][1], g0 * w3r[3][0]));
-          } else {
-            dv = *reinterpret_cast<const float4*>(p_dout + (mrow + gid) * 16 + 4 * q);
-          }
-          if (p_mbits) {
-            const uint32_t m = p_mbits[(mrow + gid) * 4 + q];
-            dv.x = (m & 1u) ? dv.x : 0.f;
-            dv.y = (m & 2u) ? dv.y : 0.f;
-            dv.z = (m & 4u) ? dv.z : 0.f;
-            dv.w = (m & 8u) ? dv.w : 0.f;
-          }
-          if (valid && v < n_excl) dbacc = f4add(dbacc, dv);
-          r = make_float4(dv.x * sc, dv.y * sc, dv.z * sc, dv.w * sc);
+      st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int v = 16 * t + vi;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < nt0) {
+        const uint32_t info = p_pinfo[o + v];
+        const float deg = (float)((info >> 16) & 255u);
+        const bool valid = (info >> 24 & 15u) != 15u;
+        const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+        const int gid = (int)(info & 0xffffu);
+        float4 dv;
+        if (a.src3_n >= 0 && gid >= a.src3_n) {
+          const float* gr = p_g3 + (mrow + gid) * 3;
+          const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+          dv.x = fmaf(g2, w3r[0][2], fmaf(g1, w3r[0][1], g0 * w3r[0][0]));
+          dv.y = fmaf(g2, w3r[1][2], fmaf(g1, w3r[1][1], g0 * w3r[1][0]));
+          dv.z = fmaf(g2, w3r[2][2], fmaf(g1, w3r[2][1], g0 * w3r[2][0]));
+          dv.w = fmaf(g2, w3r[3][2], fmaf(g1, w3r[3][1], g0 * w3r[3][0]));
+        } else {
+          dv = *reinterpret_cast<const float4*>(p_dout + (mrow + gid) * 16 + 4 * q);
         }
-        *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
-        nw[s] = r;
+        if (p_mbits) {
+          const uint32_t m = p_mbits[(mrow + gid) * 4 + q];
+          dv.x = (m & 1u) ? dv.x : 0.f;
+          dv.y = (m & 2u) ? dv.y : 0.f;
+          dv.z = (m & 4u) ? dv.z : 0.f;
+          dv.w = (m & 8u) ? dv.w : 0.f;
+        }
+        if (valid && v < n_excl) dbacc = f4add(dbacc, dv);
+        r = make_float4(dv.x * sc, dv.y * sc, dv.z * sc, dv.w * sc);
       }
+      if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
+      if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, r);     // (outside every run-time branch)
     }
     if (a.has_dw) {   // db: this wave's sums over its exclusive vertices
       float4 d = dbacc;
@@ -325,13 +327,8 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
       if (vi == 0) *reinterpret_cast<float4*>(wdb + w * 16 + 4 * q) = d;
     }
   }
-#pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) {
-    acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
-    mfma4(acc[s], wa, nw[s]);
-  }
   MVH_STAMPX(1);
-  __syncthreads();      // rows, lists, coefv, wdb staged
+  __syncthreads();      // rows, lists, coefv, xinfo, wdb staged
   MVH_STAMPX(2);
   if (a.has_dw && tid < 16) {   // db partial of the workgroup: entries (order K, q = c_out, j = 0) of slab 0
     float d = 0.f;
@@ -339,61 +336,43 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     for (int ww = 0; ww < NW; ++ww) d += wdb[ww * 16 + tid];
     p_part[(long long)wg * tile + (K * 16 + tid) * 4] = d;
   }
-  // A operand of the weight gradient: D^1/2 x of the exclusive vertices, [c_in = vi][vertex 4 g + q]; 0 elsewhere
-  const float* xlane = p_x + mrow * 16 + vi;
-  auto x_of = [&](int g, float keep) -> float {     // (g < ng: the slots 4 g .. + 3 exist)
-    const uint32_t info = p_pinfo[o + 4 * g + q];
-    const float deg = (float)((info >> 16) & 255u);
-    const float is = ((info >> 28) & 1u) ? (deg > 0.f ? __builtin_sqrtf(deg) : 1.0f) : 0.f;
-    return xlane[(long long)(info & 0xffffu) * 16] * (is * keep);
+  // ---- weight gradient: wave w owns the groups g = w + NW i; chunk s = its groups i in [s CH, (s + 1) CH)
+  const float* xlane = p_x + mrow * 16 + vi;     // A operand: [c_in = vi][vertex 4 g + q]
+  constexpr int PD = 2;                          // chunks whose x loads are in flight ahead of the one being consumed
+  uint32_t xi[PD + 1][CH];
+  float xv[PD + 1][CH];
+  v4f t0, t1;
+  // (addresses: lane base + compile-time offsets -- no clamped indices, which the compiler would hoist out of the order
+  //  loop as one register per group and spill; a group past the wave's last one reads LDS it does not use, weight 0)
+  const uint32_t* xinfo_l = xinfo + 4 * w + q;
+  const float* ub_l = u + (size_t)(4 * w + q) * kRowF + vi;
+  auto dw_issue = [&](int s) {      // (branch-free: a slot past the exclusive set reads row 0 with weight 0)
+    if (s >= SLOTS) return;
+    uint32_t inf[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) inf[i] = xinfo_l[4 * NW * (s * CH + i)];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      xi[s % (PD + 1)][i] = inf[i];
+      xv[s % (PD + 1)][i] = xlane[(long long)(inf[i] & 0xffffu) * 16];
+    }
   };
-  if constexpr (XREG) {
+  auto dw_consume = [&](int s) {      // (no run-time branch around a matrix instruction: the compiler spills the tiles there)
 #pragma unroll
-    for (int gs = 0; gs < GSLOTS; ++gs) {
-      const int g = gs * NW + w;
-      xa[gs] = 0.f;
-      if (g < ng) xa[gs] = x_of(g, 1.0f);
+    for (int i = 0; i < CH; ++i) {
+      const bool on = w + NW * (s * CH + i) < ng;
+      const float is = __builtin_sqrtf((float)(xi[s % (PD + 1)][i] >> 16));   // D^1/2 (0 off the exclusive set / past the end)
+      float b = ub_l[(size_t)4 * NW * (s * CH + i) * kRowF];
+      b = on ? b : 0.f;
+      if (i & 1) t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s % (PD + 1)][i] * is, b, t1, 0, 0, 0);
+      else t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s % (PD + 1)][i] * is, b, t0, 0, 0, 0);
     }
-  }
-  // dW_k tile of this wave: sum over its 4-vertex groups of  (D^1/2 x)^T u_k  (u_k rows from LDS) -> wpart[w];
-  // dw_flush, behind the next barrier: the waves' tiles summed in wave order -> the workgroup's partial tile
-  auto dw_pass = [&](int k) {
-    if (!a.has_dw) return;
-    v4f t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (XREG) {
-#pragma unroll
-      for (int gs = 0; gs < GSLOTS; gs += 2) {
-        const int g = gs * NW + w;
-        if (g < ng) {
-          const float b0 = u[(size_t)(4 * g + q) * kRowF + vi];
-          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gs], b0, t0, 0, 0, 0);
-        }
-        if (gs + 1 < GSLOTS && g + NW < ng) {
-          const float b1 = u[(size_t)(4 * (g + NW) + q) * kRowF + vi];
-          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gs + 1 < GSLOTS ? gs + 1 : gs], b1, t1, 0, 0, 0);
-        }
-      }
-    } else {
-      // four groups per round: their x loads (L2) and LDS reads are issued together
-      for (int g = w; g < ng; g += 4 * NW) {
-        float xv[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int gg = min(g + i * NW, ng - 1);        // (past the end: a valid group, weight 0)
-          const float keep = (g + i * NW < ng) ? 1.0f : 0.f;
-          xv[i] = x_of(gg, keep);
-          bv[i] = u[(size_t)(4 * gg + q) * kRowF + vi];
-        }
-        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], bv[0], t0, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], bv[1], t1, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], bv[2], t0, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], bv[3], t1, 0, 0, 0);
-      }
-    }
-    (void)k;
+  };
+  auto dw_store = [&]() {   // this wave's tile of the order -> wpart[w]
     *reinterpret_cast<float4*>(wpart + w * 256 + lane * 4) =
         make_float4(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], t0[3] + t1[3]);
   };
+  // behind a barrier: the waves' tiles summed in wave order -> the workgroup's partial tile of order k
   auto dw_flush = [&](int k) {
     if (!a.has_dw || tid >= 256) return;
     float d = 0.f;
@@ -408,22 +387,30 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     const int ntk = (c[1 + min(a.R, K - 1 - k)] + 15) >> 4;
     const float sc = (k == 1) ? 0.5f : 1.0f;
     load_w(k);
-    dw_pass(k - 1);
-    __builtin_amdgcn_sched_barrier(0);
+    t0 = (v4f){0.f, 0.f, 0.f, 0.f};
+    t1 = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (a.has_dw) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) dw_issue(s);
+    }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int t = s * NW + w;
-      if (t < ntk) {
+      if (a.has_dw) dw_issue(s + PD);
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these loads down to their use, two slots on)
+      if (s < SU || t < ntk) {
         const int v = 16 * t + vi;
         const uint4 id = *reinterpret_cast<const uint4*>(smem + (size_t)v * kRowB + 64);
         const float cc = coefv[v] * sc;
         const float4 g = gather8(lane_base, id);
-        nw[s] = make_float4(fmaf(cc, g.x, -pv[s].x), fmaf(cc, g.y, -pv[s].y), fmaf(cc, g.z, -pv[s].z),
-                            fmaf(cc, g.w, -pv[s].w));
-        if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, nw[s]);   // (tiles past the last output tile: unused columns)
+        st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
+                            fmaf(cc, g.w, -st[s].w));
+        if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);   // (tiles past the last output tile: unused columns)
       }
+      if (a.has_dw) dw_consume(s);        // dW_{k-1}: the rows in LDS are still u_{k-1}
       __builtin_amdgcn_sched_barrier(0);   // one slot's gathers in flight at a time (registers)
     }
+    if (a.has_dw) dw_store();
     MVH_STAMPX(3 + 3 * (k - 1));
     __syncthreads();
     MVH_STAMPX(4 + 3 * (k - 1));
@@ -432,15 +419,29 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
       const int t = s * NW + w;
       if (t < ntk) {
         float4* own = reinterpret_cast<float4*>(u + (size_t)(16 * t + vi) * kRowF + 4 * q);
-        pv[s] = *own;
-        *own = nw[s];
+        const float4 old = *own;
+        *own = st[s];
+        st[s] = old;
       }
     }
     dw_flush(k - 1);
     __syncthreads();
     MVH_STAMPX(5 + 3 * (k - 1));
   }
-  dw_pass(K - 1);
+  if (a.has_dw) {   // dW_{K-1}: the rows are u_{K-1} now
+    t0 = (v4f){0.f, 0.f, 0.f, 0.f};
+    t1 = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PD; ++s) dw_issue(s);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      dw_issue(s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      dw_consume(s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dw_store();
+  }
   __syncthreads();      // (also: the last dW pass has read its rows)
   dw_flush(K - 1);
   MVH_STAMPX(26);
@@ -512,17 +513,20 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
 #ifdef MVH_STAMP
 MVH_STAMP_READER(mvh_debug_read_stamps_patch)
 #endif
+
 // ------------------------------------------------------------------------------------------------------------- host
 // rows + lists, -2 / deg, and (backward) the waves' dW tiles / db sums of one order
 static size_t patch_lds_bytes(const mvh_patch_plan_t* pl, int bwd_waves = 16) {
-  return (size_t)(pl->max_rows + 1) * kRowB + (size_t)pl->max_rows * 4 + (size_t)bwd_waves * (256 + 16) * 4;
+  const size_t fwd = (size_t)(pl->max_rows + 1) * kRowB + (size_t)pl->max_rows * 4;
+  if (bwd_waves <= 0) return fwd;
+  return fwd + (size_t)bwd_waves * (256 + 16) * 4 + (size_t)1344 * 4;    // (4 NW SLOTS CH group slots, every block size)
 }
 
 // register-array sizes per block size (whole tiles / groups per wave of the largest patch the LDS admits: 106 tiles)
 template <int THREADS> struct PatchCfg;
-template <> struct PatchCfg<1024> { static constexpr int S = 7, AF = 6, AB = 6, G = 22; static constexpr bool XREG = false; };
-template <> struct PatchCfg<768> { static constexpr int S = 9, AF = 8, AB = 8, G = 30; static constexpr bool XREG = false; };
-template <> struct PatchCfg<512> { static constexpr int S = 14, AF = 11, AB = 12, G = 44; static constexpr bool XREG = true; };
+template <> struct PatchCfg<1024> { static constexpr int S = 7, AF = 6, AB = 6, G = 21; };
+template <> struct PatchCfg<768> { static constexpr int S = 9, AF = 8, AB = 7, G = 27; };
+template <> struct PatchCfg<512> { static constexpr int S = 14, AF = 11, AB = 11, G = 42; };
 
 static int fwd_threads() { const int t = dbg().patch_fwd_threads; return (t == 512 || t == 768 || t == 1024) ? t : 1024; }
 static int bwd_threads() { const int t = dbg().patch_bwd_threads; return (t == 512 || t == 768 || t == 1024) ? t : 512; }
@@ -545,7 +549,7 @@ bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if ((lap->flags & need) != need) return false;
   if (pl->n_vertices != N || pl->n_patches < 1 || K - 1 > pl->n_rings) return false;
-  if (patch_lds_bytes(pl) > 160 * 1024 || pl->max_rows % 16 != 0 || pl->max_rows < 16) return false;
+  if (patch_lds_bytes(pl, bwd_threads() / 64) > 160 * 1024 || pl->max_rows % 16 != 0 || pl->max_rows < 16) return false;
   return cfg_fits_rt(pl, fwd_threads()) && cfg_fits_rt(pl, bwd_threads());
 }
 
@@ -583,12 +587,12 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   return launch_fwd_t<512>(st, pl, x, W, bias, out, bits, d);
 }
 
-template <int THREADS>
+template <int THREADS, int SU>
 static int launch_bwd_t(hipStream_t st, const mvh_patch_plan_t* pl, const float* dout, const uint8_t* mbits,
                         const float* g3, const float* w3, const float* x, const float* W, float* dx, float* part,
                         PatchDims d) {
   using C = PatchCfg<THREADS>;
-  auto kern = k_patch_bwd<THREADS, C::S, C::AB, C::G, C::XREG>;
+  auto kern = k_patch_bwd<THREADS, C::S, C::AB, C::G, SU>;
   const size_t lds = patch_lds_bytes(pl, THREADS / 64);
   static LdsAttr attr;
   if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
@@ -624,9 +628,14 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
     defer->p_is_x = 1; defer->Cin = 16; defer->Cout = 16; defer->db_mode = db ? 1 : 0; defer->dW = dW; defer->db = db;
     defer->S = nullptr;
   }
-  if (th == 1024) return launch_bwd_t<1024>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
-  if (th == 768) return launch_bwd_t<768>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
-  return launch_bwd_t<512>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
+  // slots that are core tiles for every wave of every patch (>= min_core / 16 / waves, rounded down)
+  const int su = (pl->min_core / 16) / (th / 64);
+  if (th == 1024) return su >= 5 ? launch_bwd_t<1024, 5>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
+                                 : launch_bwd_t<1024, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
+  if (th == 768) return su >= 6 ? launch_bwd_t<768, 6>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
+                                : launch_bwd_t<768, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
+  return su >= 10 ? launch_bwd_t<512, 10>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
+                  : launch_bwd_t<512, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
 }
 
 }  // namespace mvh

@@ -65,7 +65,7 @@ class PatchPlanStruct(ctypes.Structure):
     """mvh_patch_plan_t (built by meshvae_hip/patches.py)"""
     _fields_ = [("n_patches", ctypes.c_int32), ("n_rings", ctypes.c_int32), ("n_vertices", ctypes.c_int32),
                 ("max_rows", ctypes.c_int32), ("max_core", ctypes.c_int32), ("max_excl", ctypes.c_int32),
-                ("n_pool_rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_pool_rows", ctypes.c_int32), ("min_core", ctypes.c_int32),
                 ("poff", ctypes.c_void_p), ("cnt", ctypes.c_void_p), ("pinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p),
                 ("prow_off", ctypes.c_void_p), ("prow_gid", ctypes.c_void_p), ("prow_ptr", ctypes.c_void_p),
                 ("pcol", ctypes.c_void_p), ("pval", ctypes.c_void_p), ("pool_rowptr", ctypes.c_void_p)]

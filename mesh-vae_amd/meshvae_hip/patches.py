@@ -30,9 +30,10 @@ MAX_DEG = 8
 LDS_BYTES = 160 * 1024
 
 
-def lds_bytes(rows16):
-    """LDS a workgroup of the patch kernels needs for a patch of `rows16` (tile-padded) local vertices."""
-    return (rows16 + 1) * ROW_STRIDE_16B * 16 + rows16 * 4 + 16 * (256 + 16) * 4
+def lds_bytes(rows16, n_excl=0):
+    """LDS a workgroup of the patch kernels needs for a patch of `rows16` (tile-padded) local vertices, `n_excl` of
+    them exclusive: rows + lists, -2 / deg, the backward's per-wave dW tiles (16 waves) and its x-row table."""
+    return (rows16 + 1) * ROW_STRIDE_16B * 16 + rows16 * 4 + 16 * (256 + 16) * 4 + 1344 * 4
 
 
 def _adjacency(n, rows, cols):
@@ -240,7 +241,7 @@ class PatchPlan:
         self._dev = {}
 
     def lds_bytes(self):
-        return lds_bytes(self.max_rows)
+        return lds_bytes(self.max_rows, int(self.cnt[:, 0].max()))
 
     def work_ratio(self, K):
         """vertex-orders the patches compute / vertex-orders of the mesh (>= 1: the halo's redundancy)"""
@@ -263,7 +264,7 @@ class PatchPlan:
                 if t[k].numel() == 0:
                     t[k] = torch.zeros(1, dtype=t[k].dtype, device=dev)
             s = PatchPlanStruct(self.n_patches, self.n_rings, self.n, self.max_rows, int(self.cnt[:, 1].max()),
-                                int(self.cnt[:, 0].max()), self.n_pool_rows, 0,
+                                int(self.cnt[:, 0].max()), self.n_pool_rows, int(self.cnt[:, 1].min()),
                                 t["poff"].data_ptr(), t["cnt"].data_ptr(), t["pinfo"].data_ptr(), t["ell"].data_ptr(),
                                 t["prow_off"].data_ptr(), t["prow_gid"].data_ptr(), t["prow_ptr"].data_ptr(),
                                 t["pcol"].data_ptr(), t["pval"].data_ptr(),
@@ -303,7 +304,7 @@ def build_plan(n, rows, cols, n_rings, pool_t=None, min_patches=None, max_patche
     plan = None
     ptr, adj = _adjacency(n, rows, cols)
     if n >= 2 * TILE and int((ptr[1:] - ptr[:-1]).max()) <= MAX_DEG and n < 65536:
-        p0 = min_patches if min_patches is not None else max(1, -(-n // 1300))
+        p0 = min_patches if min_patches is not None else max(1, -(-n // 1280))    # (exclusive sets of <= 1 296 vertices: the kernels' group slots)
         for n_parts in range(p0, max_patches + 1):
             parts = partition(n, ptr, adj, n_parts)
             cand = PatchPlan(n, n_rings, parts, ptr, adj, pool_t)
