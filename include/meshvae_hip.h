@@ -107,6 +107,7 @@ typedef struct mvh_patch_plan {
   const int32_t* pcol;
   const float* pval;
   const int32_t* pool_rowptr; /* rowptr of the pooling operator the rows above were taken from (identity check), or NULL */
+  int32_t max_pool_nnz, reserved; /* most pooling entries (pcol / pval) of one patch */
 } mvh_patch_plan_t;
 
 /* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh

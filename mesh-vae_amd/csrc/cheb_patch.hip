@@ -10,11 +10,18 @@
 //   * LDS   : T_{k-1} of every local vertex as a 16-float row; row stride 80 B: the 16 B behind the row spread a 16-lane
 //             group's float4 gathers over all banks AND hold the vertex's neighbour list (8 LOCAL ids, padded ELL);
 //             -2 / deg per vertex behind the rows (a register per tile slot otherwise);
-//   * lanes : lane l of a wave = (vertex l & 15 of a 16-vertex tile, channel quad l >> 4): the float4 a lane gathers /
-//             holds IS the B operand of v_mfma_f32_16x16x4_f32 (k index = l >> 4) for the four k-steps of 16 channels,
-//             and with A = the weight column W_k[4 (l >> 4) + s][l & 15] the product lands as D[cout][vertex]: lane l
-//             holds the four output channels 4 (l >> 4) .. + 3 of ITS OWN vertex -- no shuffle, no LDS round trip;
-//   * input-side recurrence (no Clenshaw): out accumulates T_k W_k in one accumulator tile per 16 vertices over k.
+//   * lanes : lane l of a wave = (vertex l & 15 of a 16-vertex tile, channel quad l >> 4): the float4 a lane reads of
+//             its own vertex IS the B operand of v_mfma_f32_16x16x4_f32 (k index = l >> 4) for the four k-steps of 16
+//             channels, and with A = the weight column W_k[4 (l >> 4) + s][l & 15] the product lands as D[cout][vertex]:
+//             lane l holds the four output channels 4 (l >> 4) .. + 3 of ITS OWN vertex -- no shuffle;
+//   * input-side recurrence (no Clenshaw): out accumulates T_k W_k in one accumulator tile per 16 vertices over k;
+//   * forward: every wave gathers AND feeds the matrix pipe with the rows it has just formed (registers);
+//   * backward, WAVE ROLES: the first NWR waves of a workgroup run the recurrence (LDS gathers + VALU, no accumulators:
+//             registers for two tiles' gathers in flight), the other NWD waves do all the matrix work one order behind,
+//             reading u_{k-1} rows from LDS while the recurrence waves gather them for u_k -- the two instruction streams
+//             share each SIMD (matrix pipe beside VALU / LDS), no global load and no run-time branch sits between matrix
+//             instructions, and the weight gradient's x rows stay in the matrix waves' registers.  (The forward in this
+//             form: 44 against 35 us -- its matrix work is a quarter of the backward's and the split costs gather waves.)
 // L = -D^-1/2 A D^-1/2 on unit weights is applied in scaled variables u = D^-1/2 T (no edge values):
 //   u_k = -(2 / deg) sum_{j in N(i)} u_{k-1}[j] - u_{k-2}   (u_1: factor 1),   T_k W_k = D^1/2 (u_k W_k),
 // so the D^1/2 is applied once to the accumulated rows.  Isolated vertices (deg = 0): s = 1, no gather.
@@ -40,6 +47,7 @@ struct PatchDims {
   int src3_n;           // lazy rows: dout rows >= src3_n are g3[v][0..3) w3^T (ConvIO::src3_*), -1 = all rows stored
   int n_part;           // B * P * waves (partial tiles per slab)
   int has_dw, has_dx;
+  int pool_lds;         // the pooling entries of every patch fit the LDS behind its core rows
 };
 
 __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) {
@@ -68,6 +76,35 @@ __device__ __forceinline__ float4 gather8(const unsigned char* lane_base, const 
   return g;
 }
 
+__device__ __forceinline__ float4 ldq(const unsigned char* lane_base, uint32_t id5) {
+  return *reinterpret_cast<const float4*>(lane_base + (id5 << 4));
+}
+// the same for TWO tiles, software-pipelined by hand: four rows of one tile are summed while four of the other are in
+// flight (one tile alone is three dependent LDS round trips with nothing of the wave in between; a pair costs four)
+__device__ __forceinline__ void gather8x2(const unsigned char* lane_base, const uint4& ia, const uint4& ib, float4& ga,
+                                          float4& gb) {
+  const float4 a0 = ldq(lane_base, ia.x & 0xffffu), a1 = ldq(lane_base, ia.x >> 16);
+  const float4 a2 = ldq(lane_base, ia.y & 0xffffu), a3 = ldq(lane_base, ia.y >> 16);
+  const float4 b0 = ldq(lane_base, ib.x & 0xffffu), b1 = ldq(lane_base, ib.x >> 16);
+  const float4 b2 = ldq(lane_base, ib.y & 0xffffu), b3 = ldq(lane_base, ib.y >> 16);
+  asm volatile("" ::: "memory");
+  ga = f4add(f4add(a0, a1), f4add(a2, a3));
+  const float4 a4 = ldq(lane_base, ia.z & 0xffffu), a5 = ldq(lane_base, ia.z >> 16);
+  const float4 a6 = ldq(lane_base, ia.w & 0xffffu), a7 = ldq(lane_base, ia.w >> 16);
+  asm volatile("" ::: "memory");
+  gb = f4add(f4add(b0, b1), f4add(b2, b3));
+  const float4 b4 = ldq(lane_base, ib.z & 0xffffu), b5 = ldq(lane_base, ib.z >> 16);
+  const float4 b6 = ldq(lane_base, ib.w & 0xffffu), b7 = ldq(lane_base, ib.w >> 16);
+  asm volatile("" ::: "memory");
+  ga = f4add(ga, f4add(f4add(a4, a5), f4add(a6, a7)));
+  gb = f4add(gb, f4add(f4add(b4, b5), f4add(b6, b7)));
+  asm volatile("" ::: "memory");
+}
+
+// pin a value where it is computed (without a consumer in the gather phase the compiler sinks the sums of a tile down to
+// the swap behind the barrier and keeps -- spills -- the 32 gathered registers per tile until then)
+__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // acc (D[c_out quad][vertex]) += W-column registers (A, k-steps 0..3) x the lane's float4 (B)
 __device__ __forceinline__ void mfma4(v4f& acc, const float (&wa)[4], const float4& t) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0], t.x, acc, 0, 0, 0);
@@ -77,8 +114,10 @@ __device__ __forceinline__ void mfma4(v4f& acc, const float (&wa)[4], const floa
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-// SLOTS >= tiles of the largest patch / waves; ASLOTS >= tiles of its exclusive vertices / waves
-template <int THREADS, int SLOTS, int ASLOTS>
+// SLOTS >= tiles of the largest patch / waves; ASLOTS >= tiles of its exclusive vertices / waves.
+// SU: the first SU tile slots of every wave are core tiles in every patch, i.e. needed at every order: no run-time test
+// around them, so that they form one basic block and the scheduler overlaps the LDS round trips of neighbouring slots.
+template <int THREADS, int SLOTS, int ASLOTS, int SU>
 __global__ void __launch_bounds__(THREADS)
 k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const float* __restrict__ p_bias,
             float* __restrict__ p_out, uint8_t* __restrict__ p_bits, const int32_t* __restrict__ p_poff,
@@ -98,6 +137,19 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
   float* u = reinterpret_cast<float*>(smem);                                            // [rows16 + 1][kRowF]
   float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);          // [rows16]
   const unsigned char* lane_base = smem + 16 * q;
+  // this lane's row in tile slot s: byte offset (16 (s NW + w) + vi) 80 -- up to 133 KB, beyond the 16-bit offset field of
+  // the DS instructions: three bases 48 KB apart that the compiler cannot fold (else it keeps one address register per
+  // slot, hoisted out of the order loop: 7 .. 14 registers, spilled)
+  int kb1 = 49152, kb2 = 98304;
+  asm volatile("" : "+v"(kb1), "+v"(kb2));
+  unsigned char* const row_b0 = smem + (size_t)(16 * w + vi) * kRowB;
+  unsigned char* row_b1 = row_b0 + kb1;
+  unsigned char* row_b2 = row_b0 + kb2;
+  auto rowp = [&](int s) -> unsigned char* {
+    const int off = s * NW * 16 * kRowB;
+    return off < 49152 ? row_b0 + off : off < 98304 ? row_b1 + (off - 49152) : row_b2 + (off - 98304);
+  };
+  const float* coef_l = coefv + 16 * w + vi;      // + s NW 16
   MVH_STAMPX(0);
 
   for (int i = tid; i < rows16; i += THREADS) {
@@ -150,13 +202,33 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
     const int ntk = (c[1 + min(a.R, K - 1 - k)] + 15) >> 4;
     const float sc = (k == 1) ? 0.5f : 1.0f;
     load_w(k);
+    // (the lists and coefficients never change, and without a run-time test around their loads the compiler would hoist
+    //  them out of the order loop into ~10 registers per slot pair: the bases are re-derived opaquely every order)
+    asm volatile("" : "+v"(kb1), "+v"(kb2));
+    row_b1 = row_b0 + kb1;
+    row_b2 = row_b0 + kb2;
+    coef_l = coefv + 16 * w + vi + (kb2 - 2 * kb1);
+    // the SU unconditional slots in pairs (gather8x2), the others one by one behind their run-time test
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
+    for (int s = 0; s + 1 < SU; s += 2) {
+      const uint4 ia = *reinterpret_cast<const uint4*>(rowp(s) + 64);
+      const uint4 ib = *reinterpret_cast<const uint4*>(rowp(s + 1) + 64);
+      const float ca = coef_l[s * NW * 16] * sc, cb = coef_l[(s + 1) * NW * 16] * sc;
+      float4 ga, gb;
+      gather8x2(lane_base, ia, ib, ga, gb);
+      st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
+      st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
+                              fmaf(cb, gb.w, -st[s + 1].w));
+      if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);
+      if (s + 1 < ASLOTS) mfma4(acc[s + 1 < ASLOTS ? s + 1 : 0], wa, st[s + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = SU & ~1; s < SLOTS; ++s) {
       const int t = s * NW + w;
-      if (t < ntk) {
-        const int v = 16 * t + vi;
-        const uint4 id = *reinterpret_cast<const uint4*>(smem + (size_t)v * kRowB + 64);
-        const float cc = coefv[v] * sc;
+      if (s < SU || t < ntk) {
+        const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
+        const float cc = coef_l[s * NW * 16] * sc;
         const float4 g = gather8(lane_base, id);
         st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
                             fmaf(cc, g.w, -st[s].w));
@@ -172,7 +244,7 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
     for (int s = 0; s < SLOTS; ++s) {
       const int t = s * NW + w;
       if (t < ntk) {
-        float4* own = reinterpret_cast<float4*>(u + (size_t)(16 * t + vi) * kRowF + 4 * q);
+        float4* own = reinterpret_cast<float4*>(rowp(s) + 16 * q);
         const float4 old = *own;
         *own = st[s];
         st[s] = old;
@@ -207,14 +279,10 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
-// GSLOTS >= 4-vertex groups of the largest exclusive set / waves.  The weight gradient of order k - 1 rides in order k's
-// slot loop: slot s issues the x loads of its chunk of the wave's groups, gathers, and then feeds the matrix pipe with
-// that chunk (A = D^1/2 x from L2, B = u_{k-1} rows from LDS), so the loads' latency sits under a slot's gathers and the
-// matrix instructions of both gradients are spread between the LDS bursts.
-// SU: the first SU tile slots of every wave are core tiles in every patch (needed at every order): no run-time test
-// around them, i.e. no control flow between the x prefetch and its use (the waitcnt pass then counts exactly).
-template <int THREADS, int SLOTS, int ASLOTS, int GSLOTS, int SU>
-__global__ void __launch_bounds__(THREADS)
+// RS >= tiles of the largest patch / NWR; AS >= core tiles / NWD; GS >= 4-vertex groups of the largest exclusive set / NWD;
+// SU: see k_patch_fwd
+template <int NWR, int NWD, int RS, int AS, int GS, int SU>
+__global__ void __launch_bounds__((NWR + NWD) * 64)
 k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbits, const float* __restrict__ p_g3,
             const float* __restrict__ p_w3, const float* __restrict__ p_x, const float* __restrict__ p_W,
             float* __restrict__ p_dx, float* __restrict__ p_part, const int32_t* __restrict__ p_poff,
@@ -222,8 +290,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
             const int32_t* __restrict__ p_prow_off, const int32_t* __restrict__ p_prow_gid,
             const int32_t* __restrict__ p_prow_ptr, const int32_t* __restrict__ p_pcol, const float* __restrict__ p_pval,
             PatchDims a) {
-  constexpr int NW = THREADS / 64;
-  constexpr int CH = (GSLOTS + SLOTS - 1) / SLOTS;     // groups of a wave per slot
+  constexpr int THREADS = (NWR + NWD) * 64;
   extern __shared__ __align__(16) unsigned char smem[];
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int mesh = (jj / a.P) * 8 + xcd, pt = jj % a.P;
@@ -235,270 +302,341 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   const int K = a.K;
   const int n_excl = c[0], n_core = c[1];
   const int nt_all = rows16 >> 4;
-  const int nt_out = a.has_dx ? (n_core + 15) >> 4 : 0;
   const int nt0 = (c[1 + min(a.R, K - 1)] + 15) >> 4;
-  const int ng = a.has_dw ? (n_excl + 3) >> 2 : 0;          // 4-vertex groups of the weight gradient
   float* u = reinterpret_cast<float*>(smem);
   float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);   // -2 / deg per local vertex
-  float* wpart = coefv + rows16;                   // [NW][256] the waves' dW tiles of one order, [NW][16] their db sums
-  float* wdb = wpart + NW * 256;
-  uint32_t* xinfo = reinterpret_cast<uint32_t*>(wdb + NW * 16);   // [4 NW SLOTS CH] global id | max(deg, 1) << 16; 0 off the exclusive set
-  const unsigned char* lane_base = smem + 16 * q;
+  float* wpart = coefv + rows16;                   // [NWD][256] the matrix waves' dW tiles of one order
+  float* wdb = wpart + NWD * 256;                  // [NWR][16] the recurrence waves' db sums
   MVH_STAMPX(0);
 
   for (int i = tid; i < rows16; i += THREADS) {
     *reinterpret_cast<uint4*>(smem + (size_t)i * kRowB + 64) = reinterpret_cast<const uint4*>(p_ell)[o + i];
-    const uint32_t info = p_pinfo[o + i];
-    const uint32_t dg = (info >> 16) & 255u;
-    coefv[i] = dg > 0u ? -2.0f * __builtin_amdgcn_rcpf((float)dg) : 0.f;
-    if (i < 4 * NW * SLOTS * CH) xinfo[i] = ((info >> 28) & 1u) && a.has_dw ? ((info & 0xffffu) | (max(dg, 1u) << 16)) : 0u;
+    const float deg = (float)((p_pinfo[o + i] >> 16) & 255u);
+    coefv[i] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
   }
-  for (int i = rows16 + tid; i < 4 * NW * SLOTS * CH; i += THREADS) xinfo[i] = 0u;   // (every group slot of every wave exists)
   if (tid < kRowF / 4) reinterpret_cast<float4*>(u + (size_t)rows16 * kRowF)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  float4 st[SLOTS];     // (see k_patch_fwd)
-  v4f acc[ASLOTS];
-  float wa[4];
-  auto load_w = [&](int k) {   // A = W_k^T: [c_in = vi][c_out = 4 q + s]
-    const float4 t = *reinterpret_cast<const float4*>(p_W + k * 256 + vi * 16 + 4 * q);
-    wa[0] = t.x; wa[1] = t.y; wa[2] = t.z; wa[3] = t.w;
-  };
-  load_w(0);
   const long long mrow = (long long)mesh * a.N;
   const int wg = mesh * a.P + pt;          // this workgroup's partial tile (one per slab)
   const int tile = (K + 1) * 64;
+
+  if (w < NWR) {
+    // ================================================== recurrence waves (see k_patch_fwd): rows = dpre = dout * relu'
+    const unsigned char* lane_base = smem + 16 * q;
+    // (three row bases 48 KB apart, opaque to the compiler: see k_patch_fwd)
+    int kb1 = 49152, kb2 = 98304;
+    asm volatile("" : "+v"(kb1), "+v"(kb2));
+    unsigned char* const row_b0 = smem + (size_t)(16 * w + vi) * kRowB;
+    unsigned char* row_b1 = row_b0 + kb1;
+    unsigned char* row_b2 = row_b0 + kb2;
+    auto rowp = [&](int s) -> unsigned char* {
+      const int off = s * NWR * 16 * kRowB;
+      return off < 49152 ? row_b0 + off : off < 98304 ? row_b1 + (off - 49152) : row_b2 + (off - 98304);
+    };
+    const float* coef_l = coefv + 16 * w + vi;      // + s NWR 16
+    float4 st[RS];
+    {
+      float w3r[4][3];      // lazy rows: this lane's four columns of W3 [16][3]
+      if (a.src3_n >= 0) {
 #pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
-  {
-    // lazy rows: this lane's four columns of W3 [16][3]
-    float w3r[4][3];
-    if (a.src3_n >= 0) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+          for (int t = 0; t < 3; ++t) w3r[i][t] = p_w3[(4 * q + i) * 3 + t];
+      }
+      float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      // two phases, no run-time branch in either: every slot's plan word first, then every slot's row (the loads of all
+      // RS slots are in flight together; a slot past the patch reads its last row and is discarded)
+      uint32_t inf[RS];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) w3r[i][t] = p_w3[(4 * q + i) * 3 + t];
-    }
-    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < RS; ++s) inf[s] = p_pinfo[o + min(16 * (s * NWR + w) + vi, rows16 - 1)];
+      const bool lazy = a.src3_n >= 0;
+      if (lazy) {
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int t = s * NW + w;
-      st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int v = 16 * t + vi;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < nt0) {
-        const uint32_t info = p_pinfo[o + v];
+        for (int s = 0; s < RS; ++s) {
+          const float* gr = p_g3 + (mrow + (inf[s] & 0xffffu)) * 3;
+          st[s] = make_float4(gr[0], gr[1], gr[2], 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < RS; ++s) st[s] = *reinterpret_cast<const float4*>(p_dout + (mrow + (inf[s] & 0xffffu)) * 16 + 4 * q);
+      }
+      uint32_t mb[RS];
+#pragma unroll
+      for (int s = 0; s < RS; ++s) mb[s] = p_mbits ? (uint32_t)p_mbits[(mrow + (inf[s] & 0xffffu)) * 4 + q] : 15u;
+      bool fix_any = false;
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        const int t = s * NWR + w;
+        const int v = 16 * t + vi;
+        const uint32_t info = inf[s];
         const float deg = (float)((info >> 16) & 255u);
-        const bool valid = (info >> 24 & 15u) != 15u;
+        const bool valid = t < nt0 && (info >> 24 & 15u) != 15u;
         const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-        const int gid = (int)(info & 0xffffu);
-        float4 dv;
-        if (a.src3_n >= 0 && gid >= a.src3_n) {
-          const float* gr = p_g3 + (mrow + gid) * 3;
-          const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+        float4 dv = st[s];
+        if (lazy) {
+          const float g0 = dv.x, g1 = dv.y, g2 = dv.z;
           dv.x = fmaf(g2, w3r[0][2], fmaf(g1, w3r[0][1], g0 * w3r[0][0]));
           dv.y = fmaf(g2, w3r[1][2], fmaf(g1, w3r[1][1], g0 * w3r[1][0]));
           dv.z = fmaf(g2, w3r[2][2], fmaf(g1, w3r[2][1], g0 * w3r[2][0]));
           dv.w = fmaf(g2, w3r[3][2], fmaf(g1, w3r[3][1], g0 * w3r[3][0]));
-        } else {
-          dv = *reinterpret_cast<const float4*>(p_dout + (mrow + gid) * 16 + 4 * q);
+          fix_any = fix_any || (valid && (int)(info & 0xffffu) < a.src3_n);
         }
-        if (p_mbits) {
-          const uint32_t m = p_mbits[(mrow + gid) * 4 + q];
-          dv.x = (m & 1u) ? dv.x : 0.f;
-          dv.y = (m & 2u) ? dv.y : 0.f;
-          dv.z = (m & 4u) ? dv.z : 0.f;
-          dv.w = (m & 8u) ? dv.w : 0.f;
-        }
+        const uint32_t m = mb[s];
+        dv.x = (m & 1u) ? dv.x : 0.f;
+        dv.y = (m & 2u) ? dv.y : 0.f;
+        dv.z = (m & 4u) ? dv.z : 0.f;
+        dv.w = (m & 8u) ? dv.w : 0.f;
         if (valid && v < n_excl) dbacc = f4add(dbacc, dv);
-        r = make_float4(dv.x * sc, dv.y * sc, dv.z * sc, dv.w * sc);
+        if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = make_float4(dv.x * sc, dv.y * sc, dv.z * sc, dv.w * sc);
+        st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
-      if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, r);     // (outside every run-time branch)
-    }
-    if (a.has_dw) {   // db: this wave's sums over its exclusive vertices
-      float4 d = dbacc;
+      // the few STORED rows of a lazy gradient (the connected block of the layer above, ConvIO::src3_n rows of the mesh):
+      // the lanes that own one redo their slot from the stored row (rare: one divergent pass, skipped by every other wave)
+      if (__builtin_amdgcn_ballot_w64(fix_any) != 0ull) {
 #pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        d.x += __shfl_xor(d.x, m, 64);
-        d.y += __shfl_xor(d.y, m, 64);
-        d.z += __shfl_xor(d.z, m, 64);
-        d.w += __shfl_xor(d.w, m, 64);
+        for (int s = 0; s < RS; ++s) {
+          const int t = s * NWR + w;
+          const int v = 16 * t + vi;
+          const uint32_t info = inf[s];
+          const int gid = (int)(info & 0xffffu);
+          if (t < nt0 && (info >> 24 & 15u) != 15u && gid < a.src3_n) {
+            const float deg = (float)((info >> 16) & 255u);
+            const float sc = deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f;
+            const float* gr = p_g3 + (mrow + gid) * 3;
+            const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+            float4 lz, dv = *reinterpret_cast<const float4*>(p_dout + (mrow + gid) * 16 + 4 * q);
+            lz.x = fmaf(g2, w3r[0][2], fmaf(g1, w3r[0][1], g0 * w3r[0][0]));
+            lz.y = fmaf(g2, w3r[1][2], fmaf(g1, w3r[1][1], g0 * w3r[1][0]));
+            lz.z = fmaf(g2, w3r[2][2], fmaf(g1, w3r[2][1], g0 * w3r[2][0]));
+            lz.w = fmaf(g2, w3r[3][2], fmaf(g1, w3r[3][1], g0 * w3r[3][0]));
+            const uint32_t m = mb[s];
+            dv.x = (m & 1u) ? dv.x : 0.f; lz.x = (m & 1u) ? lz.x : 0.f;
+            dv.y = (m & 2u) ? dv.y : 0.f; lz.y = (m & 2u) ? lz.y : 0.f;
+            dv.z = (m & 4u) ? dv.z : 0.f; lz.z = (m & 4u) ? lz.z : 0.f;
+            dv.w = (m & 8u) ? dv.w : 0.f; lz.w = (m & 8u) ? lz.w : 0.f;
+            if (v < n_excl) dbacc = make_float4(dbacc.x + (dv.x - lz.x), dbacc.y + (dv.y - lz.y), dbacc.z + (dv.z - lz.z), dbacc.w + (dv.w - lz.w));
+            *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = make_float4(dv.x * sc, dv.y * sc, dv.z * sc, dv.w * sc);
+          }
+        }
       }
-      if (vi == 0) *reinterpret_cast<float4*>(wdb + w * 16 + 4 * q) = d;
-    }
-  }
-  MVH_STAMPX(1);
-  __syncthreads();      // rows, lists, coefv, xinfo, wdb staged
-  MVH_STAMPX(2);
-  if (a.has_dw && tid < 16) {   // db partial of the workgroup: entries (order K, q = c_out, j = 0) of slab 0
-    float d = 0.f;
+      if (a.has_dw) {   // db: this wave's sums over its exclusive vertices
+        float4 d = dbacc;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) d += wdb[ww * 16 + tid];
-    p_part[(long long)wg * tile + (K * 16 + tid) * 4] = d;
-  }
-  // ---- weight gradient: wave w owns the groups g = w + NW i; chunk s = its groups i in [s CH, (s + 1) CH)
-  const float* xlane = p_x + mrow * 16 + vi;     // A operand: [c_in = vi][vertex 4 g + q]
-  constexpr int PD = 2;                          // chunks whose x loads are in flight ahead of the one being consumed
-  uint32_t xi[PD + 1][CH];
-  float xv[PD + 1][CH];
-  v4f t0, t1;
-  // (addresses: lane base + compile-time offsets -- no clamped indices, which the compiler would hoist out of the order
-  //  loop as one register per group and spill; a group past the wave's last one reads LDS it does not use, weight 0)
-  const uint32_t* xinfo_l = xinfo + 4 * w + q;
-  const float* ub_l = u + (size_t)(4 * w + q) * kRowF + vi;
-  auto dw_issue = [&](int s) {      // (branch-free: a slot past the exclusive set reads row 0 with weight 0)
-    if (s >= SLOTS) return;
-    uint32_t inf[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) inf[i] = xinfo_l[4 * NW * (s * CH + i)];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      xi[s % (PD + 1)][i] = inf[i];
-      xv[s % (PD + 1)][i] = xlane[(long long)(inf[i] & 0xffffu) * 16];
-    }
-  };
-  auto dw_consume = [&](int s) {      // (no run-time branch around a matrix instruction: the compiler spills the tiles there)
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const bool on = w + NW * (s * CH + i) < ng;
-      const float is = __builtin_sqrtf((float)(xi[s % (PD + 1)][i] >> 16));   // D^1/2 (0 off the exclusive set / past the end)
-      float b = ub_l[(size_t)4 * NW * (s * CH + i) * kRowF];
-      b = on ? b : 0.f;
-      if (i & 1) t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s % (PD + 1)][i] * is, b, t1, 0, 0, 0);
-      else t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s % (PD + 1)][i] * is, b, t0, 0, 0, 0);
-    }
-  };
-  auto dw_store = [&]() {   // this wave's tile of the order -> wpart[w]
-    *reinterpret_cast<float4*>(wpart + w * 256 + lane * 4) =
-        make_float4(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], t0[3] + t1[3]);
-  };
-  // behind a barrier: the waves' tiles summed in wave order -> the workgroup's partial tile of order k
-  auto dw_flush = [&](int k) {
-    if (!a.has_dw || tid >= 256) return;
-    float d = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) d += wpart[ww * 256 + tid];
-    // element tid = (lane l = tid >> 2, register r = tid & 3) of the D tile: c_in = 4 (l >> 4) + r, c_out = l & 15
-    const int l = tid >> 2, r = tid & 3;
-    p_part[((long long)(l >> 4) * a.n_part + wg) * tile + (k * 16 + (l & 15)) * 4 + r] = d;
-  };
-
-  for (int k = 1; k < K; ++k) {
-    const int ntk = (c[1 + min(a.R, K - 1 - k)] + 15) >> 4;
-    const float sc = (k == 1) ? 0.5f : 1.0f;
-    load_w(k);
-    t0 = (v4f){0.f, 0.f, 0.f, 0.f};
-    t1 = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (a.has_dw) {
-#pragma unroll
-      for (int s = 0; s < PD; ++s) dw_issue(s);
-    }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int t = s * NW + w;
-      if (a.has_dw) dw_issue(s + PD);
-      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these loads down to their use, two slots on)
-      if (s < SU || t < ntk) {
-        const int v = 16 * t + vi;
-        const uint4 id = *reinterpret_cast<const uint4*>(smem + (size_t)v * kRowB + 64);
-        const float cc = coefv[v] * sc;
-        const float4 g = gather8(lane_base, id);
-        st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
-                            fmaf(cc, g.w, -st[s].w));
-        if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);   // (tiles past the last output tile: unused columns)
+        for (int m = 1; m < 16; m <<= 1) {
+          d.x += __shfl_xor(d.x, m, 64);
+          d.y += __shfl_xor(d.y, m, 64);
+          d.z += __shfl_xor(d.z, m, 64);
+          d.w += __shfl_xor(d.w, m, 64);
+        }
+        if (vi == 0) *reinterpret_cast<float4*>(wdb + w * 16 + 4 * q) = d;
       }
-      if (a.has_dw) dw_consume(s);        // dW_{k-1}: the rows in LDS are still u_{k-1}
-      __builtin_amdgcn_sched_barrier(0);   // one slot's gathers in flight at a time (registers)
     }
-    if (a.has_dw) dw_store();
-    MVH_STAMPX(3 + 3 * (k - 1));
+    MVH_STAMPX(1);
     __syncthreads();
-    MVH_STAMPX(4 + 3 * (k - 1));
+    MVH_STAMPX(2);
+    for (int k = 1; k < K; ++k) {
+      const int ntk = (c[1 + min(a.R, K - 1 - k)] + 15) >> 4;
+      const float sc = (k == 1) ? 0.5f : 1.0f;
+      asm volatile("" : "+v"(kb1), "+v"(kb2));     // (see k_patch_fwd: no hoisting of the lists out of the order loop)
+      row_b1 = row_b0 + kb1;
+      row_b2 = row_b0 + kb2;
+      coef_l = coefv + 16 * w + vi + (kb2 - 2 * kb1);
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int t = s * NW + w;
-      if (t < ntk) {
-        float4* own = reinterpret_cast<float4*>(u + (size_t)(16 * t + vi) * kRowF + 4 * q);
-        const float4 old = *own;
-        *own = st[s];
-        st[s] = old;
+      for (int s = 0; s + 1 < SU; s += 2) {      // the unconditional slots in pairs (gather8x2)
+        const uint4 ia = *reinterpret_cast<const uint4*>(rowp(s) + 64);
+        const uint4 ib = *reinterpret_cast<const uint4*>(rowp(s + 1) + 64);
+        const float ca = coef_l[s * NWR * 16] * sc, cb = coef_l[(s + 1) * NWR * 16] * sc;
+        float4 ga, gb;
+        gather8x2(lane_base, ia, ib, ga, gb);
+        st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
+        st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
+                                fmaf(cb, gb.w, -st[s + 1].w));
+        pin(st[s]);
+        pin(st[s + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = SU & ~1; s < RS; ++s) {
+        const int t = s * NWR + w;
+        if (s < SU || t < ntk) {
+          const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
+          const float cc = coef_l[s * NWR * 16] * sc;
+          const float4 g = gather8(lane_base, id);
+          st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
+                              fmaf(cc, g.w, -st[s].w));
+          pin(st[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      MVH_STAMPX(3 + 3 * (k - 1));
+      __syncthreads();
+      MVH_STAMPX(4 + 3 * (k - 1));
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        const int t = s * NWR + w;
+        if (t < ntk) {
+          float4* own = reinterpret_cast<float4*>(rowp(s) + 16 * q);
+          const float4 old = *own;
+          *own = st[s];
+          st[s] = old;
+        }
+      }
+      __syncthreads();
+      MVH_STAMPX(5 + 3 * (k - 1));
+    }
+    __syncthreads();      // (the matrix waves' pass over u_{K-1})
+    if (!a.has_dx || a.n_pool_rows <= 0) return;
+    __syncthreads();      // dX rows staged in LDS
+  } else {
+    // ================================================== matrix waves, one order behind the recurrence:
+    //   dX tile a NWD + wd:  acc += W_k^T (A) x u_k rows (B);   dW_k: groups g = gs NWD + wd: x^T (A, registers) x u_k rows (B)
+    const int wd = w - NWR;
+    const int dtid = tid - NWR * 64;
+    v4f acc[AS];
+    float xa[GS];
+    float wa[4];
+    auto load_w = [&](int k) {   // A = W_k^T: [c_in = vi][c_out = 4 q + s]
+      const float4 t = *reinterpret_cast<const float4*>(p_W + k * 256 + vi * 16 + 4 * q);
+      wa[0] = t.x; wa[1] = t.y; wa[2] = t.z; wa[3] = t.w;
+    };
+    // A operand of the weight gradient: D^1/2 x of the exclusive vertices, [c_in = vi][vertex 4 g + q]; 0 elsewhere
+    const int ng = a.has_dw ? (n_excl + 3) >> 2 : 0;
+    {   // (two phases, branch-free: every group's plan word, then every group's x -- 2 round trips, not 2 GS)
+      uint32_t xinf[GS];
+#pragma unroll
+      for (int gs = 0; gs < GS; ++gs) xinf[gs] = p_pinfo[o + min(4 * (gs * NWD + wd) + q, rows16 - 1)];
+#pragma unroll
+      for (int gs = 0; gs < GS; ++gs) xa[gs] = p_x[(mrow + (xinf[gs] & 0xffffu)) * 16 + vi];
+#pragma unroll
+      for (int gs = 0; gs < GS; ++gs) {
+        const float deg = (float)((xinf[gs] >> 16) & 255u);
+        const bool on = (gs * NWD + wd) < ng && ((xinf[gs] >> 28) & 1u);
+        xa[gs] *= on ? (deg > 0.f ? __builtin_sqrtf(deg) : 1.0f) : 0.f;
       }
     }
-    dw_flush(k - 1);
+#pragma unroll
+    for (int i = 0; i < AS; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const float* tile_l = u + (size_t)(16 * wd + vi) * kRowF + 4 * q;     // dX: this lane's quad of tile wd (+ a NWD 16 rows)
+    const float* grp_l = u + (size_t)(4 * wd + q) * kRowF + vi;           // dW: row 4 wd + q, channel vi (+ gs NWD 4 rows)
+    auto pass = [&](int k) {      // both gradients' share of order k from the u_k rows in LDS
+      if (a.has_dx) {
+        load_w(k);
+#pragma unroll
+        for (int i = 0; i < AS; ++i) {
+          const float4 b = *reinterpret_cast<const float4*>(tile_l + (size_t)i * NWD * 16 * kRowF);
+          mfma4(acc[i], wa, b);
+        }
+      }
+      if (a.has_dw) {
+        v4f t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gs = 0; gs < GS; gs += 2) {
+          const float b0 = grp_l[(size_t)gs * NWD * 4 * kRowF];
+          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gs], b0, t0, 0, 0, 0);
+          if (gs + 1 < GS) {
+            const float b1 = grp_l[(size_t)(gs + 1) * NWD * 4 * kRowF];
+            t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gs + 1 < GS ? gs + 1 : gs], b1, t1, 0, 0, 0);
+          }
+        }
+        *reinterpret_cast<float4*>(wpart + wd * 256 + lane * 4) =
+            make_float4(t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], t0[3] + t1[3]);
+      }
+    };
+    // behind a barrier: the matrix waves' tiles summed in wave order -> the workgroup's partial tile of order k
+    auto flush = [&](int k) {
+      if (!a.has_dw || dtid >= 256) return;
+      float d = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWD; ++ww) d += wpart[ww * 256 + dtid];
+      // element dtid = (lane l = dtid >> 2, register r = dtid & 3) of the D tile: c_in = 4 (l >> 4) + r, c_out = l & 15
+      const int l = dtid >> 2, r = dtid & 3;
+      p_part[((long long)(l >> 4) * a.n_part + wg) * tile + (k * 16 + (l & 15)) * 4 + r] = d;
+    };
+    MVH_STAMPX(1);
     __syncthreads();
-    MVH_STAMPX(5 + 3 * (k - 1));
-  }
-  if (a.has_dw) {   // dW_{K-1}: the rows are u_{K-1} now
-    t0 = (v4f){0.f, 0.f, 0.f, 0.f};
-    t1 = (v4f){0.f, 0.f, 0.f, 0.f};
+    MVH_STAMPX(2);
+    if (a.has_dw && dtid < 16) {   // db partial of the workgroup: entries (order K, q = c_out, j = 0) of slab 0
+      float d = 0.f;
 #pragma unroll
-    for (int s = 0; s < PD; ++s) dw_issue(s);
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      dw_issue(s + PD);
-      __builtin_amdgcn_sched_barrier(0);
-      dw_consume(s);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ww = 0; ww < NWR; ++ww) d += wdb[ww * 16 + dtid];
+      p_part[(long long)wg * tile + (K * 16 + dtid) * 4] = d;
     }
-    dw_store();
-  }
-  __syncthreads();      // (also: the last dW pass has read its rows)
-  dw_flush(K - 1);
-  MVH_STAMPX(26);
-  if (!a.has_dx) return;
-
-  // ---- dX rows (D^1/2 applied): straight to memory, or through LDS into the rows of the pooling operator
-  if (a.n_pool_rows <= 0) {
+    for (int k = 1; k < K; ++k) {
+      pass(k - 1);
+      MVH_STAMPX(3 + 3 * (k - 1));
+      __syncthreads();
+      MVH_STAMPX(4 + 3 * (k - 1));
+      flush(k - 1);
+      __syncthreads();
+      MVH_STAMPX(5 + 3 * (k - 1));
+    }
+    pass(K - 1);
+    MVH_STAMPX(26);
+    __syncthreads();
+    flush(K - 1);
+    if (!a.has_dx) return;
+    // ---- dX rows (D^1/2 applied): straight to memory, or through LDS into the rows of the pooling operator
+    if (a.n_pool_rows <= 0) {
 #pragma unroll
-    for (int s = 0; s < ASLOTS; ++s) {
-      const int t = s * NW + w;
-      const int v = 16 * t + vi;
-      if (t < nt_out && v < n_excl) {
-        const uint32_t info = p_pinfo[o + v];
-        const float deg = (float)((info >> 16) & 255u);
-        const float is = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
-        *reinterpret_cast<float4*>(p_dx + (mrow + (info & 0xffffu)) * 16 + 4 * q) =
-            make_float4(acc[s][0] * is, acc[s][1] * is, acc[s][2] * is, acc[s][3] * is);
+      for (int i = 0; i < AS; ++i) {
+        const int v = 16 * (i * NWD + wd) + vi;
+        if (v < n_excl) {
+          const uint32_t info = p_pinfo[o + v];
+          const float deg = (float)((info >> 16) & 255u);
+          const float is = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
+          *reinterpret_cast<float4*>(p_dx + (mrow + (info & 0xffffu)) * 16 + 4 * q) =
+              make_float4(acc[i][0] * is, acc[i][1] * is, acc[i][2] * is, acc[i][3] * is);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < AS; ++i) {
+      const int v = 16 * (i * NWD + wd) + vi;
+      if (v < ((n_core + 15) & ~15)) {
+        const float cf = coefv[v];      // -2 / deg (0: isolated)  ->  D^1/2 = sqrt(-2 / cf)
+        const float is = cf < 0.f ? __builtin_sqrtf(-2.0f * __builtin_amdgcn_rcpf(cf)) : 1.0f;
+        *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) =
+            make_float4(acc[i][0] * is, acc[i][1] * is, acc[i][2] * is, acc[i][3] * is);
       }
     }
-    return;
+    __syncthreads();
   }
-#pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) {
-    const int t = s * NW + w;
-    const int v = 16 * t + vi;
-    if (t < nt_out) {
-      const uint32_t info = p_pinfo[o + v];
-      const float deg = (float)((info >> 16) & 255u);
-      const float is = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
-      *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) =
-          make_float4(acc[s][0] * is, acc[s][1] * is, acc[s][2] * is, acc[s][3] * is);
-    }
-  }
-  __syncthreads();
+  // ---- every wave: the rows of the pooling operator's transpose this patch forms, from the dX rows in LDS.  The patch's
+  // (column, value) entries are first copied behind the core rows (halo rows, coefficients and dW tiles are dead by now):
+  // the row loops then run on LDS alone -- the operator's rows reach 54 entries, 14 dependent global round trips
   MVH_STAMPX(27);
   const int r0 = p_prow_off[pt], nrow = p_prow_off[pt + 1] - r0;
   const int* __restrict__ rp = p_prow_ptr + r0 + pt;
+  const int ebase = rp[0], ne = rp[nrow] - ebase;
+  uint2* ent = reinterpret_cast<uint2*>(smem + (size_t)((n_core + 15) & ~15) * kRowB);
+  const bool staged = a.pool_lds != 0;     // (host: the largest patch's entries fit)
+  if (staged) {
+    for (int i = tid; i < ne; i += THREADS) ent[i] = make_uint2((uint32_t)p_pcol[ebase + i], __float_as_uint(p_pval[ebase + i]));
+    __syncthreads();
+  }
   for (int it = tid; it < nrow * 4; it += THREADS) {
     const int i = it >> 2, qq = it & 3;
-    const int e0 = rp[i], e1 = rp[i + 1];
+    const int e0 = rp[i] - ebase, e1 = rp[i + 1] - ebase;
     float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // four taps per round (loads issued together); taps past the row end: a valid entry with weight 0, so the sums
-    // stay in the operator's entry order (the arithmetic of k_spmm<.., EXACT>)
-    for (int e = e0; e < e1; e += 4) {
-      float wv[4];
-      int cc[4];
+    // eight taps per round (loads issued together); taps past the row end: a valid entry with weight 0, so the sums stay
+    // in the operator's entry order
+    for (int e = e0; e < e1; e += 8) {
+      float wv[8];
+      int cc[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 8; ++t) {
         const int ee = min(e + t, e1 - 1);
-        cc[t] = p_pcol[ee];
-        wv[t] = (e + t < e1) ? p_pval[ee] : 0.f;
+        uint2 cv;
+        if (staged) cv = ent[ee];
+        else cv = make_uint2((uint32_t)p_pcol[ebase + ee], __float_as_uint(p_pval[ebase + ee]));
+        cc[t] = (int)cv.x;
+        wv[t] = (e + t < e1) ? __uint_as_float(cv.y) : 0.f;
       }
-      float4 n[4];
+      float4 n[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) n[t] = *reinterpret_cast<const float4*>(u + (size_t)cc[t] * kRowF + 4 * qq);
+      for (int t = 0; t < 8; ++t) n[t] = *reinterpret_cast<const float4*>(u + (size_t)cc[t] * kRowF + 4 * qq);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 8; ++t) {
         sacc.x = __fadd_rn(sacc.x, __fmul_rn(wv[t], n[t].x));
         sacc.y = __fadd_rn(sacc.y, __fmul_rn(wv[t], n[t].y));
         sacc.z = __fadd_rn(sacc.z, __fmul_rn(wv[t], n[t].z));
@@ -515,31 +653,21 @@ MVH_STAMP_READER(mvh_debug_read_stamps_patch)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------- host
-// rows + lists, -2 / deg, and (backward) the waves' dW tiles / db sums of one order
-static size_t patch_lds_bytes(const mvh_patch_plan_t* pl, int bwd_waves = 16) {
+// wave roles and register-array sizes (the largest patch the LDS admits: 106 tiles; exclusive sets of <= 1 280 vertices)
+struct FwdCfg { static constexpr int THREADS = 1024, S = 7, A = 6, SU = 4; };      // (uniform waves: tile slots, output-tile slots)
+struct BwdCfg { static constexpr int NWR = 8, NWD = 8, RS = 14, AS = 11, GS = 40, SU = 10; };
+
+// rows + lists, -2 / deg, and (backward) the matrix waves' dW tiles of one order + the recurrence waves' db sums
+static size_t patch_lds_bytes(const mvh_patch_plan_t* pl, bool bwd) {
   const size_t fwd = (size_t)(pl->max_rows + 1) * kRowB + (size_t)pl->max_rows * 4;
-  if (bwd_waves <= 0) return fwd;
-  return fwd + (size_t)bwd_waves * (256 + 16) * 4 + (size_t)1344 * 4;    // (4 NW SLOTS CH group slots, every block size)
+  return bwd ? fwd + (size_t)(BwdCfg::NWD * 256 + BwdCfg::NWR * 16) * 4 : fwd;
 }
 
-// register-array sizes per block size (whole tiles / groups per wave of the largest patch the LDS admits: 106 tiles)
-template <int THREADS> struct PatchCfg;
-template <> struct PatchCfg<1024> { static constexpr int S = 7, AF = 6, AB = 6, G = 21; };
-template <> struct PatchCfg<768> { static constexpr int S = 9, AF = 8, AB = 7, G = 27; };
-template <> struct PatchCfg<512> { static constexpr int S = 14, AF = 11, AB = 11, G = 42; };
-
-static int fwd_threads() { const int t = dbg().patch_fwd_threads; return (t == 512 || t == 768 || t == 1024) ? t : 1024; }
-static int bwd_threads() { const int t = dbg().patch_bwd_threads; return (t == 512 || t == 768 || t == 1024) ? t : 512; }
-
-template <int THREADS>
 static bool cfg_fits(const mvh_patch_plan_t* pl) {
-  constexpr int NW = THREADS / 64;
-  using C = PatchCfg<THREADS>;
-  return cdiv(pl->max_rows / 16, NW) <= C::S && cdiv(cdiv(pl->max_excl, 16), NW) <= C::AF &&
-         cdiv(cdiv(pl->max_core, 16), NW) <= C::AB && cdiv(cdiv(pl->max_excl, 4), NW) <= C::G;
-}
-static bool cfg_fits_rt(const mvh_patch_plan_t* pl, int threads) {
-  return threads == 1024 ? cfg_fits<1024>(pl) : threads == 768 ? cfg_fits<768>(pl) : cfg_fits<512>(pl);
+  const int tiles = pl->max_rows / 16;
+  return cdiv(tiles, FwdCfg::THREADS / 64) <= FwdCfg::S && cdiv(cdiv(pl->max_excl, 16), FwdCfg::THREADS / 64) <= FwdCfg::A &&
+         cdiv(tiles, BwdCfg::NWR) <= BwdCfg::RS && cdiv(cdiv(pl->max_core, 16), BwdCfg::NWD) <= BwdCfg::AS &&
+         cdiv(cdiv(pl->max_excl, 4), BwdCfg::NWD) <= BwdCfg::GS;
 }
 
 bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
@@ -549,8 +677,8 @@ bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if ((lap->flags & need) != need) return false;
   if (pl->n_vertices != N || pl->n_patches < 1 || K - 1 > pl->n_rings) return false;
-  if (patch_lds_bytes(pl, bwd_threads() / 64) > 160 * 1024 || pl->max_rows % 16 != 0 || pl->max_rows < 16) return false;
-  return cfg_fits_rt(pl, fwd_threads()) && cfg_fits_rt(pl, bwd_threads());
+  if (patch_lds_bytes(pl, true) > 160 * 1024 || pl->max_rows % 16 != 0 || pl->max_rows < 16) return false;
+  return cfg_fits(pl);
 }
 
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
@@ -559,46 +687,23 @@ size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
   return (size_t)4 * B * pl->n_patches * (K + 1) * 64 * sizeof(float) + 256;
 }
 
-template <int THREADS>
-static int launch_fwd_t(hipStream_t st, const mvh_patch_plan_t* pl, const float* x, const float* W, const float* bias,
-                        float* out, uint8_t* bits, const PatchDims& d) {
-  using C = PatchCfg<THREADS>;
-  auto kern = k_patch_fwd<THREADS, C::S, C::AF>;
-  const size_t lds = patch_lds_bytes(pl, 0);
-  static LdsAttr attr;
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
-  const int grid = ((d.B + 7) / 8) * 8 * d.P;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, x, W, bias, out, bits, pl->poff, pl->cnt, pl->pinfo,
-                     pl->ell, d);
-  MVH_LAUNCH_CHECK();
-  return MVH_OK;
-}
-
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
                      uint8_t* bits, int B, int N, int K, int act) {
   const mvh_patch_plan_t* pl = lap->patch;
   MVH_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "patch_fwd: tensors must be 16-byte aligned");
+  MVH_REQUIRE(cfg_fits(pl), "patch_fwd: the plan does not fit the kernel's register arrays");
   PatchDims d{};
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = act;
-  const int th = fwd_threads();
-  MVH_REQUIRE(cfg_fits_rt(pl, th), "patch_fwd: the plan does not fit the %d-thread kernel", th);
-  if (th == 1024) return launch_fwd_t<1024>(st, pl, x, W, bias, out, bits, d);
-  if (th == 768) return launch_fwd_t<768>(st, pl, x, W, bias, out, bits, d);
-  return launch_fwd_t<512>(st, pl, x, W, bias, out, bits, d);
-}
-
-template <int THREADS, int SU>
-static int launch_bwd_t(hipStream_t st, const mvh_patch_plan_t* pl, const float* dout, const uint8_t* mbits,
-                        const float* g3, const float* w3, const float* x, const float* W, float* dx, float* part,
-                        PatchDims d) {
-  using C = PatchCfg<THREADS>;
-  auto kern = k_patch_bwd<THREADS, C::S, C::AB, C::G, SU>;
-  const size_t lds = patch_lds_bytes(pl, THREADS / 64);
-  static LdsAttr attr;
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
+  using C = FwdCfg;
+  // slots that are core tiles for every wave of every patch
+  const bool su_ok = (pl->min_core / 16) / (C::THREADS / 64) >= C::SU;
+  auto kern = su_ok ? k_patch_fwd<C::THREADS, C::S, C::A, C::SU> : k_patch_fwd<C::THREADS, C::S, C::A, 0>;
+  const size_t lds = patch_lds_bytes(pl, false);
+  static LdsAttr attr[2];
+  if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, dout, mbits, g3, w3, x, W, dx, part, pl->poff,
-                     pl->cnt, pl->pinfo, pl->ell, pl->prow_off, pl->prow_gid, pl->prow_ptr, pl->pcol, pl->pval, d);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, W, bias, out, bits, pl->poff, pl->cnt,
+                     pl->pinfo, pl->ell, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }
@@ -613,14 +718,15 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
               "patch_bwd: tensors must be 16-byte aligned");
   MVH_REQUIRE(!pooled || pl->n_pool_rows > 0, "patch_bwd: the plan carries no pooling rows");
   MVH_REQUIRE(dx || dW, "patch_bwd: nothing to compute");
-  const int th = bwd_threads();
-  MVH_REQUIRE(cfg_fits_rt(pl, th), "patch_bwd: the plan does not fit the %d-thread kernel", th);
+  MVH_REQUIRE(cfg_fits(pl), "patch_bwd: the plan does not fit the kernel's register arrays");
   PatchDims d{};
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = 0;
   d.n_pool_rows = pooled ? pl->n_pool_rows : 0;
   d.src3_n = g3 ? src3_n : -1;
   d.n_part = B * pl->n_patches;
   d.has_dw = dW ? 1 : 0; d.has_dx = dx ? 1 : 0;
+  // free LDS behind the dX rows of the largest core at the pooling epilogue: halo rows, zero row, coefficients, dW tiles
+  d.pool_lds = pooled && (size_t)pl->max_pool_nnz * 8 + (size_t)((pl->max_core + 15) / 16 * 16) * kRowB <= patch_lds_bytes(pl, true);
   if (dW) {
     MVH_REQUIRE(x && part && defer && part_bytes >= patch_part_bytes(lap, B, K), "patch_bwd: partial-tile buffer too small");
     *defer = DwReduceEntry{};
@@ -628,14 +734,17 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
     defer->p_is_x = 1; defer->Cin = 16; defer->Cout = 16; defer->db_mode = db ? 1 : 0; defer->dW = dW; defer->db = db;
     defer->S = nullptr;
   }
-  // slots that are core tiles for every wave of every patch (>= min_core / 16 / waves, rounded down)
-  const int su = (pl->min_core / 16) / (th / 64);
-  if (th == 1024) return su >= 5 ? launch_bwd_t<1024, 5>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
-                                 : launch_bwd_t<1024, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
-  if (th == 768) return su >= 6 ? launch_bwd_t<768, 6>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
-                                : launch_bwd_t<768, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
-  return su >= 10 ? launch_bwd_t<512, 10>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d)
-                  : launch_bwd_t<512, 0>(st, pl, dout, mbits, g3, w3, x, W, dx, part, d);
+  using C = BwdCfg;
+  const bool su_ok = (pl->min_core / 16) / C::NWR >= C::SU;
+  auto kern = su_ok ? k_patch_bwd<C::NWR, C::NWD, C::RS, C::AS, C::GS, C::SU> : k_patch_bwd<C::NWR, C::NWD, C::RS, C::AS, C::GS, 0>;
+  const size_t lds = patch_lds_bytes(pl, true);
+  static LdsAttr attr[2];
+  if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
+  const int grid = ((d.B + 7) / 8) * 8 * d.P;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((C::NWR + C::NWD) * 64), lds, st, dout, mbits, g3, w3, x, W, dx, part,
+                     pl->poff, pl->cnt, pl->pinfo, pl->ell, pl->prow_off, pl->prow_gid, pl->prow_ptr, pl->pcol, pl->pval, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
 }
 
 }  // namespace mvh

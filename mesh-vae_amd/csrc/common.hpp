@@ -132,7 +132,6 @@ struct DebugCfg {
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
   int patch_flush_first = 0;   // 1: the step forks the weight-gradient items queued so far BEFORE a patch backward launch
-  int patch_fwd_threads = 0, patch_bwd_threads = 0;   // block size of the patch kernels (512 / 768 / 1024; 0 = built-in)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();

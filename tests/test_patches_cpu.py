@@ -77,7 +77,8 @@ def test_plan_invariants_and_numpy_model(fixture, pooled):
         assert np.array_equal(deg[:tot], (ptr[1:] - ptr[:-1])[gid[:tot]])
         for r in range(plan.n_rings + 1):
             assert (ring[:c[1 + r]] <= r).all()
-        # every list of a vertex that will be gathered FOR holds exactly its neighbours, as local ids x 5, in adjacency order
+        # every list of a vertex that will be gathered FOR holds exactly its neighbours, as local ids x 5 (any order:
+        # the builder permutes a list against LDS bank conflicts)
         e = plan.ell[o:o + rows16].astype(np.int64)
         nb = np.stack([e & 0xffff, e >> 16], -1).reshape(rows16, 8)
         assert (nb % pt.ROW_STRIDE_16B == 0).all()
@@ -86,7 +87,7 @@ def test_plan_invariants_and_numpy_model(fixture, pooled):
         for li in range(0, inner, 37):
             want = adj[ptr[gid[li]]:ptr[gid[li] + 1]]
             have = nb[li][nb[li] < rows16]
-            assert np.array_equal(gid[have], want)
+            assert np.array_equal(np.sort(gid[have]), np.sort(want))
         assert (nb[inner:] == rows16).all()
         if pooled:
             r0, r1 = int(plan.prow_off[p]), int(plan.prow_off[p + 1])
@@ -106,6 +107,7 @@ def test_plan_invariants_and_numpy_model(fixture, pooled):
     np.testing.assert_allclose(pt.emulate_forward(plan, x, W), _dense_cheb(n, rows, cols, x, W), rtol=0, atol=1e-12)
     np.testing.assert_allclose(pt.emulate_forward(plan, x, W[:3]), _dense_cheb(n, rows, cols, x, W[:3]), rtol=0, atol=1e-12)
     assert 1.0 <= plan.work_ratio(6) < 1.7
+    assert pt.gather_conflict_model(plan) < 1.6          # (2.2 before the lists are permuted)
 
 
 def test_graphs_without_a_compact_cut_get_no_plan():
