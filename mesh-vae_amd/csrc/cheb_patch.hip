@@ -54,50 +54,69 @@ __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
-// sum of the 8 neighbour rows' quads: lane_base = LDS byte address of quad q of row 0, ids = 8 x (5 x local id)
-__device__ __forceinline__ float4 gather8(const unsigned char* lane_base, const uint4& id) {
+// LDS byte offset of quad q (qoff = 16 q) of the row whose id (5 x local id, one 16-bit half of w) the list holds:
+// id * 16 + qoff in ONE instruction (the compiler's and / shift / add forms take 2-3; the gather loops are bound by
+// vector-instruction issue)
+__device__ __forceinline__ unsigned addr_lo(unsigned w, unsigned qoff) {
+  unsigned r;
+  asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[0,0,0,0]" : "=v"(r) : "v"(w), "v"(qoff));
+  return r;
+}
+__device__ __forceinline__ unsigned addr_hi(unsigned w, unsigned qoff) {
+  unsigned r;
+  asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "v"(qoff));
+  return r;
+}
+__device__ __forceinline__ float4 ldq(const unsigned char* smem0, unsigned off) {
+  return *reinterpret_cast<const float4*>(smem0 + off);
+}
+
+// sum of the neighbour rows' quads: smem0 = the LDS base, qoff = 16 q, ids = 8 x (5 x local id), padw = the pad id in both
+// halves.  A list of <= 6 neighbours ends in two pads (plan: SHORT_DEG): when all 16 lists of the tile do -- 4 of 5 tiles
+// on the 5k template -- the last two gathers are skipped (wave-uniform test on the word the lane already holds).
+__device__ __forceinline__ float4 gather8(const unsigned char* smem0, unsigned qoff, const uint4& id, unsigned padw) {
   float4 g;
   {
-    const float4 n0 = *reinterpret_cast<const float4*>(lane_base + ((id.x & 0xffffu) << 4));
-    const float4 n1 = *reinterpret_cast<const float4*>(lane_base + ((id.x >> 16) << 4));
-    const float4 n2 = *reinterpret_cast<const float4*>(lane_base + ((id.y & 0xffffu) << 4));
-    const float4 n3 = *reinterpret_cast<const float4*>(lane_base + ((id.y >> 16) << 4));
+    const float4 n0 = ldq(smem0, addr_lo(id.x, qoff)), n1 = ldq(smem0, addr_hi(id.x, qoff));
+    const float4 n2 = ldq(smem0, addr_lo(id.y, qoff)), n3 = ldq(smem0, addr_hi(id.y, qoff));
     g = f4add(f4add(n0, n1), f4add(n2, n3));
   }
   asm volatile("" ::: "memory");   // (four rows in flight at a time: 16 registers instead of 32)
   {
-    const float4 n4 = *reinterpret_cast<const float4*>(lane_base + ((id.z & 0xffffu) << 4));
-    const float4 n5 = *reinterpret_cast<const float4*>(lane_base + ((id.z >> 16) << 4));
-    const float4 n6 = *reinterpret_cast<const float4*>(lane_base + ((id.w & 0xffffu) << 4));
-    const float4 n7 = *reinterpret_cast<const float4*>(lane_base + ((id.w >> 16) << 4));
-    g = f4add(g, f4add(f4add(n4, n5), f4add(n6, n7)));
+    const float4 n4 = ldq(smem0, addr_lo(id.z, qoff)), n5 = ldq(smem0, addr_hi(id.z, qoff));
+    g = f4add(g, f4add(n4, n5));
+  }
+  if (__builtin_amdgcn_ballot_w64(id.w != padw) != 0ull) {
+    const float4 n6 = ldq(smem0, addr_lo(id.w, qoff)), n7 = ldq(smem0, addr_hi(id.w, qoff));
+    g = f4add(g, f4add(n6, n7));
   }
   asm volatile("" ::: "memory");
   return g;
 }
 
-__device__ __forceinline__ float4 ldq(const unsigned char* lane_base, uint32_t id5) {
-  return *reinterpret_cast<const float4*>(lane_base + (id5 << 4));
-}
-// the same for TWO tiles, software-pipelined by hand: four rows of one tile are summed while four of the other are in
-// flight (one tile alone is three dependent LDS round trips with nothing of the wave in between; a pair costs four)
-__device__ __forceinline__ void gather8x2(const unsigned char* lane_base, const uint4& ia, const uint4& ib, float4& ga,
-                                          float4& gb) {
-  const float4 a0 = ldq(lane_base, ia.x & 0xffffu), a1 = ldq(lane_base, ia.x >> 16);
-  const float4 a2 = ldq(lane_base, ia.y & 0xffffu), a3 = ldq(lane_base, ia.y >> 16);
-  const float4 b0 = ldq(lane_base, ib.x & 0xffffu), b1 = ldq(lane_base, ib.x >> 16);
-  const float4 b2 = ldq(lane_base, ib.y & 0xffffu), b3 = ldq(lane_base, ib.y >> 16);
+// the same for TWO tiles, software-pipelined by hand: rows of one tile are summed while rows of the other are in flight
+// (one tile alone is three dependent LDS round trips with nothing of the wave in between)
+__device__ __forceinline__ void gather8x2(const unsigned char* smem0, unsigned qoff, const uint4& ia, const uint4& ib,
+                                          unsigned padw, float4& ga, float4& gb) {
+  const float4 a0 = ldq(smem0, addr_lo(ia.x, qoff)), a1 = ldq(smem0, addr_hi(ia.x, qoff));
+  const float4 a2 = ldq(smem0, addr_lo(ia.y, qoff)), a3 = ldq(smem0, addr_hi(ia.y, qoff));
+  const float4 b0 = ldq(smem0, addr_lo(ib.x, qoff)), b1 = ldq(smem0, addr_hi(ib.x, qoff));
+  const float4 b2 = ldq(smem0, addr_lo(ib.y, qoff)), b3 = ldq(smem0, addr_hi(ib.y, qoff));
   asm volatile("" ::: "memory");
   ga = f4add(f4add(a0, a1), f4add(a2, a3));
-  const float4 a4 = ldq(lane_base, ia.z & 0xffffu), a5 = ldq(lane_base, ia.z >> 16);
-  const float4 a6 = ldq(lane_base, ia.w & 0xffffu), a7 = ldq(lane_base, ia.w >> 16);
+  const float4 a4 = ldq(smem0, addr_lo(ia.z, qoff)), a5 = ldq(smem0, addr_hi(ia.z, qoff));
   asm volatile("" ::: "memory");
   gb = f4add(f4add(b0, b1), f4add(b2, b3));
-  const float4 b4 = ldq(lane_base, ib.z & 0xffffu), b5 = ldq(lane_base, ib.z >> 16);
-  const float4 b6 = ldq(lane_base, ib.w & 0xffffu), b7 = ldq(lane_base, ib.w >> 16);
+  const float4 b4 = ldq(smem0, addr_lo(ib.z, qoff)), b5 = ldq(smem0, addr_hi(ib.z, qoff));
   asm volatile("" ::: "memory");
-  ga = f4add(ga, f4add(f4add(a4, a5), f4add(a6, a7)));
-  gb = f4add(gb, f4add(f4add(b4, b5), f4add(b6, b7)));
+  ga = f4add(ga, f4add(a4, a5));
+  gb = f4add(gb, f4add(b4, b5));
+  if (__builtin_amdgcn_ballot_w64(ia.w != padw || ib.w != padw) != 0ull) {     // (either tile has a long list: both pay)
+    const float4 a6 = ldq(smem0, addr_lo(ia.w, qoff)), a7 = ldq(smem0, addr_hi(ia.w, qoff));
+    const float4 b6 = ldq(smem0, addr_lo(ib.w, qoff)), b7 = ldq(smem0, addr_hi(ib.w, qoff));
+    ga = f4add(ga, f4add(a6, a7));
+    gb = f4add(gb, f4add(b6, b7));
+  }
   asm volatile("" ::: "memory");
 }
 
@@ -134,9 +153,9 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
   const int o = p_poff[pt], rows16 = p_poff[pt + 1] - o;
   const int* __restrict__ c = p_cnt + pt * (a.R + 2);
   const int K = a.K;
+  const unsigned padw = (unsigned)(rows16 * 5) * 0x10001u;      // the list pad (the zero row), both halves of a word
   float* u = reinterpret_cast<float*>(smem);                                            // [rows16 + 1][kRowF]
   float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);          // [rows16]
-  const unsigned char* lane_base = smem + 16 * q;
   // this lane's row in tile slot s: byte offset (16 (s NW + w) + vi) 80 -- up to 133 KB, beyond the 16-bit offset field of
   // the DS instructions: three bases 48 KB apart that the compiler cannot fold (else it keeps one address register per
   // slot, hoisted out of the order loop: 7 .. 14 registers, spilled)
@@ -215,7 +234,7 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
       const uint4 ib = *reinterpret_cast<const uint4*>(rowp(s + 1) + 64);
       const float ca = coef_l[s * NW * 16] * sc, cb = coef_l[(s + 1) * NW * 16] * sc;
       float4 ga, gb;
-      gather8x2(lane_base, ia, ib, ga, gb);
+      gather8x2(smem, 16u * q, ia, ib, padw, ga, gb);
       st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
       st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
                               fmaf(cb, gb.w, -st[s + 1].w));
@@ -229,7 +248,7 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
       if (s < SU || t < ntk) {
         const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
         const float cc = coef_l[s * NW * 16] * sc;
-        const float4 g = gather8(lane_base, id);
+        const float4 g = gather8(smem, 16u * q, id, padw);
         st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
                             fmaf(cc, g.w, -st[s].w));
         if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);   // (tiles past the last output tile: unused columns)
@@ -300,6 +319,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   const int o = p_poff[pt], rows16 = p_poff[pt + 1] - o;
   const int* __restrict__ c = p_cnt + pt * (a.R + 2);
   const int K = a.K;
+  const unsigned padw = (unsigned)(rows16 * 5) * 0x10001u;      // the list pad (the zero row), both halves of a word
   const int n_excl = c[0], n_core = c[1];
   const int nt_all = rows16 >> 4;
   const int nt0 = (c[1 + min(a.R, K - 1)] + 15) >> 4;
@@ -318,11 +338,26 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   const long long mrow = (long long)mesh * a.N;
   const int wg = mesh * a.P + pt;          // this workgroup's partial tile (one per slab)
   const int tile = (K + 1) * 64;
+  // pooling epilogue (has_dx, n_pool_rows > 0): rows r0 .. r0 + nrow of the plan, entries ebase .. ebase + ne of pcol / pval
+  const bool pool = a.has_dx && a.n_pool_rows > 0;
+  const int r0 = pool ? p_prow_off[pt] : 0, nrow = pool ? p_prow_off[pt + 1] - r0 : 0;
+  const int* __restrict__ rp = p_prow_ptr + r0 + pt;
+  const int ebase = pool ? rp[0] : 0, ne = pool ? rp[nrow] - ebase : 0;
+  uint2* ent = reinterpret_cast<uint2*>(smem + (size_t)((n_core + 15) & ~15) * kRowB);   // (behind the dX rows of the core)
+  const bool staged = pool && a.pool_lds != 0;     // (host: the largest patch's entries fit there, <= 8 per recurrence lane)
+  // first item of this thread (row it >> 2, quad it & 3): its entry range and output row, fetched ahead of the barriers
+  int e0f = 0, e1f = 0, gidf = 0;
+  auto pre_item = [&]() {
+    if (pool && tid < nrow * 4) {
+      e0f = rp[tid >> 2] - ebase;
+      e1f = rp[(tid >> 2) + 1] - ebase;
+      gidf = p_prow_gid[r0 + (tid >> 2)];
+    }
+  };
 
   if (w < NWR) {
     // ================================================== recurrence waves (see k_patch_fwd): rows = dpre = dout * relu'
-    const unsigned char* lane_base = smem + 16 * q;
-    // (three row bases 48 KB apart, opaque to the compiler: see k_patch_fwd)
+      // (three row bases 48 KB apart, opaque to the compiler: see k_patch_fwd)
     int kb1 = 49152, kb2 = 98304;
     asm volatile("" : "+v"(kb1), "+v"(kb2));
     unsigned char* const row_b0 = smem + (size_t)(16 * w + vi) * kRowB;
@@ -446,7 +481,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         const uint4 ib = *reinterpret_cast<const uint4*>(rowp(s + 1) + 64);
         const float ca = coef_l[s * NWR * 16] * sc, cb = coef_l[(s + 1) * NWR * 16] * sc;
         float4 ga, gb;
-        gather8x2(lane_base, ia, ib, ga, gb);
+        gather8x2(smem, 16u * q, ia, ib, padw, ga, gb);
         st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
         st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
                                 fmaf(cb, gb.w, -st[s + 1].w));
@@ -460,7 +495,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         if (s < SU || t < ntk) {
           const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
           const float cc = coef_l[s * NWR * 16] * sc;
-          const float4 g = gather8(lane_base, id);
+          const float4 g = gather8(smem, 16u * q, id, padw);
           st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
                               fmaf(cc, g.w, -st[s].w));
           pin(st[s]);
@@ -483,9 +518,27 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
       __syncthreads();
       MVH_STAMPX(5 + 3 * (k - 1));
     }
+    // while the matrix waves run the last order: this patch's pooling entries -> registers (8 per lane), then into the LDS
+    // the halo rows, coefficients and dW tiles leave free once that pass is done
+    uint2 pe[8];
+    if (staged) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = min(tid + NWR * 64 * j, max(ne - 1, 0));
+        pe[j] = make_uint2((uint32_t)p_pcol[ebase + e], __float_as_uint(p_pval[ebase + e]));
+      }
+    }
+    pre_item();
     __syncthreads();      // (the matrix waves' pass over u_{K-1})
-    if (!a.has_dx || a.n_pool_rows <= 0) return;
-    __syncthreads();      // dX rows staged in LDS
+    if (!pool) return;
+    if (staged) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + NWR * 64 * j;
+        if (e < ne) ent[e] = pe[j];
+      }
+    }
+    __syncthreads();      // dX rows (+ pooling entries) staged in LDS
   } else {
     // ================================================== matrix waves, one order behind the recurrence:
     //   dX tile a NWD + wd:  acc += W_k^T (A) x u_k rows (B);   dW_k: groups g = gs NWD + wd: x^T (A, registers) x u_k rows (B)
@@ -571,6 +624,13 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     }
     pass(K - 1);
     MVH_STAMPX(26);
+    float isd[AS];        // D^1/2 of this lane's dX rows (from the LDS coefficients, which the recurrence waves overwrite next)
+#pragma unroll
+    for (int i = 0; i < AS; ++i) {
+      const float cf = coefv[min(16 * (i * NWD + wd) + vi, rows16 - 1)];      // -2 / deg (0: isolated)
+      isd[i] = cf < 0.f ? __builtin_sqrtf(-2.0f * __builtin_amdgcn_rcpf(cf)) : 1.0f;
+    }
+    pre_item();
     __syncthreads();
     flush(K - 1);
     if (!a.has_dx) return;
@@ -593,8 +653,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     for (int i = 0; i < AS; ++i) {
       const int v = 16 * (i * NWD + wd) + vi;
       if (v < ((n_core + 15) & ~15)) {
-        const float cf = coefv[v];      // -2 / deg (0: isolated)  ->  D^1/2 = sqrt(-2 / cf)
-        const float is = cf < 0.f ? __builtin_sqrtf(-2.0f * __builtin_amdgcn_rcpf(cf)) : 1.0f;
+        const float is = isd[i];
         *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) =
             make_float4(acc[i][0] * is, acc[i][1] * is, acc[i][2] * is, acc[i][3] * is);
       }
@@ -602,21 +661,14 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     __syncthreads();
   }
   // ---- every wave: the rows of the pooling operator's transpose this patch forms, from the dX rows in LDS.  The patch's
-  // (column, value) entries are first copied behind the core rows (halo rows, coefficients and dW tiles are dead by now):
-  // the row loops then run on LDS alone -- the operator's rows reach 54 entries, 14 dependent global round trips
+  // (column, value) entries sit behind the core rows by now (the recurrence waves fetched them during the last order):
+  // the row loops run on LDS alone -- the operator's rows reach 54 entries, 14 dependent global round trips otherwise
   MVH_STAMPX(27);
-  const int r0 = p_prow_off[pt], nrow = p_prow_off[pt + 1] - r0;
-  const int* __restrict__ rp = p_prow_ptr + r0 + pt;
-  const int ebase = rp[0], ne = rp[nrow] - ebase;
-  uint2* ent = reinterpret_cast<uint2*>(smem + (size_t)((n_core + 15) & ~15) * kRowB);
-  const bool staged = a.pool_lds != 0;     // (host: the largest patch's entries fit)
-  if (staged) {
-    for (int i = tid; i < ne; i += THREADS) ent[i] = make_uint2((uint32_t)p_pcol[ebase + i], __float_as_uint(p_pval[ebase + i]));
-    __syncthreads();
-  }
   for (int it = tid; it < nrow * 4; it += THREADS) {
     const int i = it >> 2, qq = it & 3;
-    const int e0 = rp[i] - ebase, e1 = rp[i + 1] - ebase;
+    const bool first = it == tid;
+    const int e0 = first ? e0f : rp[i] - ebase, e1 = first ? e1f : rp[i + 1] - ebase;
+    const int grow = first ? gidf : p_prow_gid[r0 + i];
     float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
     // eight taps per round (loads issued together); taps past the row end: a valid entry with weight 0, so the sums stay
     // in the operator's entry order
@@ -643,7 +695,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         sacc.w = __fadd_rn(sacc.w, __fmul_rn(wv[t], n[t].w));
       }
     }
-    *reinterpret_cast<float4*>(p_dx + ((long long)mesh * a.n_pool_rows + p_prow_gid[r0 + i]) * 16 + 4 * qq) = sacc;
+    *reinterpret_cast<float4*>(p_dx + ((long long)mesh * a.n_pool_rows + grow) * 16 + 4 * qq) = sacc;
   }
   MVH_STAMPX(28);
 }
@@ -726,7 +778,8 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   d.n_part = B * pl->n_patches;
   d.has_dw = dW ? 1 : 0; d.has_dx = dx ? 1 : 0;
   // free LDS behind the dX rows of the largest core at the pooling epilogue: halo rows, zero row, coefficients, dW tiles
-  d.pool_lds = pooled && (size_t)pl->max_pool_nnz * 8 + (size_t)((pl->max_core + 15) / 16 * 16) * kRowB <= patch_lds_bytes(pl, true);
+  d.pool_lds = pooled && pl->max_pool_nnz <= BwdCfg::NWR * 64 * 8 &&
+               (size_t)pl->max_pool_nnz * 8 + (size_t)((pl->max_core + 15) / 16 * 16) * kRowB <= patch_lds_bytes(pl, true);
   if (dW) {
     MVH_REQUIRE(x && part && defer && part_bytes >= patch_part_bytes(lap, B, K), "patch_bwd: partial-tile buffer too small");
     *defer = DwReduceEntry{};

@@ -107,7 +107,7 @@ def test_plan_invariants_and_numpy_model(fixture, pooled):
     np.testing.assert_allclose(pt.emulate_forward(plan, x, W), _dense_cheb(n, rows, cols, x, W), rtol=0, atol=1e-12)
     np.testing.assert_allclose(pt.emulate_forward(plan, x, W[:3]), _dense_cheb(n, rows, cols, x, W[:3]), rtol=0, atol=1e-12)
     assert 1.0 <= plan.work_ratio(6) < 1.7
-    assert pt.gather_conflict_model(plan) < 1.6          # (2.2 before the lists are permuted)
+    assert pt.gather_conflict_model(plan) < 48           # LDS cycles of a tile's gathers (70 before the lists are permuted and trimmed)
 
 
 def test_graphs_without_a_compact_cut_get_no_plan():
