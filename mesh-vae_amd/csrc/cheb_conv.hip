@@ -1053,9 +1053,9 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   MVH_REQUIRE(!io.out_lazy, "cheb_conv_fwd: out_lazy on a layer that is not on the split path");
   // 16 -> 16 on a level that carries a vertex-patch plan: (mesh, patch) workgroups with all channels, contraction on
   // v_mfma_f32_16x16x4_f32 (cheb_patch.hip).  No fused pooling there: the decoder's LAST stage and module-level calls.
-  if (!tx_saved && !bf && !io.x_map && !pool && patch_eligible(lap, N, Cin, Cout, K) &&
+  if (!tx_saved && !bf && !pool && patch_eligible(lap, N, Cin, Cout, K) &&
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)W) & 15) == 0)
-    return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act);
+    return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs);
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;
@@ -1244,7 +1244,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     return MVH_OK;
   }
   // vertex-patch plan on this level (cheb_patch.hip): dX (+ its pooling) and the dW / db partial tiles from ONE launch
-  if (!dout_pool && !tx_saved && !bf && !io.x_map && !dbg().no_patch_bwd && patch_eligible(lap_t, N, Cin, Cout, K) &&
+  if (!dout_pool && !tx_saved && !bf && !dbg().no_patch_bwd && patch_eligible(lap_t, N, Cin, Cout, K) &&
       (act != MVH_ACT_RELU || out_bits) &&
       (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dx_pooled | (uintptr_t)W | (uintptr_t)partial |
         (uintptr_t)defer_part) & 15) == 0) {
@@ -1256,7 +1256,8 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     if (!dW || pbytes >= patch_part_bytes(lap_t, B, K)) {
       DwReduceEntry e{};
       if (int rc = launch_patch_bwd(st, lap_t, x, W, dout, act == MVH_ACT_RELU ? out_bits : nullptr, io.src3_g, io.src3_w,
-                                    io.src3_n, pooled ? dx_pooled : dx, pooled, part, pbytes, &e, dW, db, B, N, K)) return rc;
+                                    io.src3_n, pooled ? dx_pooled : dx, pooled, part, pbytes, &e, dW, db, B, N, K, io.x_map,
+                                    io.x_bs)) return rc;
       if (dW) {
         if (defer) {
           *defer = e;

@@ -48,6 +48,7 @@ struct PatchDims {
   int n_part;           // B * P * waves (partial tiles per slab)
   int has_dw, has_dx;
   int pool_lds;         // the pooling entries of every patch fit the LDS behind its core rows
+  int x_bs;             // rows per mesh of the layer input x (N, or the mesh stride of a strided view in rows)
 };
 
 __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) {
@@ -138,8 +139,9 @@ __device__ __forceinline__ void mfma4(v4f& acc, const float (&wa)[4], const floa
 // around them, so that they form one basic block and the scheduler overlaps the LDS round trips of neighbouring slots.
 template <int THREADS, int SLOTS, int ASLOTS, int SU>
 __global__ void __launch_bounds__(THREADS)
-k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const float* __restrict__ p_bias,
-            float* __restrict__ p_out, uint8_t* __restrict__ p_bits, const int32_t* __restrict__ p_poff,
+k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, const float* __restrict__ p_W,
+            const float* __restrict__ p_bias, float* __restrict__ p_out, uint8_t* __restrict__ p_bits,
+            const int32_t* __restrict__ p_poff,
             const int32_t* __restrict__ p_cnt, const uint32_t* __restrict__ p_pinfo, const uint32_t* __restrict__ p_ell,
             PatchDims a) {
   constexpr int NW = THREADS / 64;
@@ -193,7 +195,7 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
     for (int s = 0; s < 4; ++s) wa[s] = p_W[k * 256 + (4 * q + s) * 16 + vi];
   };
   load_w(0);
-  const float* xb = p_x + (long long)mesh * a.N * 16;
+  const float* xb = p_x + (long long)mesh * a.x_bs * 16;      // (strided x, ConvIO::x_map: row v of a mesh at x_map[v])
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -207,7 +209,8 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
       const float deg = (float)((info >> 16) & 255u);
       const bool valid = (info >> 24 & 15u) != 15u;
       const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-      const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)(info & 0xffffu) * 16 + 4 * q);
+      const int xr = p_xmap ? p_xmap[info & 0xffffu] : (int)(info & 0xffffu);
+      const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)xr * 16 + 4 * q);
       r = make_float4(xv.x * sc, xv.y * sc, xv.z * sc, xv.w * sc);
     }
     if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
@@ -303,8 +306,9 @@ k_patch_fwd(const float* __restrict__ p_x, const float* __restrict__ p_W, const 
 template <int NWR, int NWD, int RS, int AS, int GS, int SU>
 __global__ void __launch_bounds__((NWR + NWD) * 64)
 k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbits, const float* __restrict__ p_g3,
-            const float* __restrict__ p_w3, const float* __restrict__ p_x, const float* __restrict__ p_W,
-            float* __restrict__ p_dx, float* __restrict__ p_part, const int32_t* __restrict__ p_poff,
+            const float* __restrict__ p_w3, const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap,
+            const float* __restrict__ p_W, float* __restrict__ p_dx, float* __restrict__ p_part,
+            const int32_t* __restrict__ p_poff,
             const int32_t* __restrict__ p_cnt, const uint32_t* __restrict__ p_pinfo, const uint32_t* __restrict__ p_ell,
             const int32_t* __restrict__ p_prow_off, const int32_t* __restrict__ p_prow_gid,
             const int32_t* __restrict__ p_prow_ptr, const int32_t* __restrict__ p_pcol, const float* __restrict__ p_pval,
@@ -557,8 +561,14 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
       uint32_t xinf[GS];
 #pragma unroll
       for (int gs = 0; gs < GS; ++gs) xinf[gs] = p_pinfo[o + min(4 * (gs * NWD + wd) + q, rows16 - 1)];
+      const float* xb = p_x + (long long)mesh * a.x_bs * 16 + vi;
+      if (p_xmap) {
 #pragma unroll
-      for (int gs = 0; gs < GS; ++gs) xa[gs] = p_x[(mrow + (xinf[gs] & 0xffffu)) * 16 + vi];
+        for (int gs = 0; gs < GS; ++gs) xa[gs] = xb[(long long)p_xmap[xinf[gs] & 0xffffu] * 16];
+      } else {
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) xa[gs] = xb[(long long)(xinf[gs] & 0xffffu) * 16];
+      }
 #pragma unroll
       for (int gs = 0; gs < GS; ++gs) {
         const float deg = (float)((xinf[gs] >> 16) & 255u);
@@ -740,12 +750,13 @@ size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
 }
 
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
-                     uint8_t* bits, int B, int N, int K, int act) {
+                     uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map, int x_bs) {
   const mvh_patch_plan_t* pl = lap->patch;
   MVH_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "patch_fwd: tensors must be 16-byte aligned");
   MVH_REQUIRE(cfg_fits(pl), "patch_fwd: the plan does not fit the kernel's register arrays");
   PatchDims d{};
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = act;
+  d.x_bs = x_map ? x_bs : N;
   using C = FwdCfg;
   // slots that are core tiles for every wave of every patch
   const bool su_ok = (pl->min_core / 16) / (C::THREADS / 64) >= C::SU;
@@ -754,7 +765,7 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   static LdsAttr attr[2];
   if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, W, bias, out, bits, pl->poff, pl->cnt,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, x_map, W, bias, out, bits, pl->poff, pl->cnt,
                      pl->pinfo, pl->ell, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
@@ -764,7 +775,8 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
 // come out of the reduction `defer` describes (launch_dw_reduce_all; the caller runs it, at once or deferred).
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
-                     float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K) {
+                     float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K,
+                     const int32_t* x_map, int x_bs) {
   const mvh_patch_plan_t* pl = lap->patch;
   MVH_REQUIRE((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)W | (uintptr_t)part) & 15) == 0,
               "patch_bwd: tensors must be 16-byte aligned");
@@ -773,6 +785,7 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   MVH_REQUIRE(cfg_fits(pl), "patch_bwd: the plan does not fit the kernel's register arrays");
   PatchDims d{};
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = 0;
+  d.x_bs = x_map ? x_bs : N;
   d.n_pool_rows = pooled ? pl->n_pool_rows : 0;
   d.src3_n = g3 ? src3_n : -1;
   d.n_part = B * pl->n_patches;
@@ -794,7 +807,7 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   static LdsAttr attr[2];
   if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3((C::NWR + C::NWD) * 64), lds, st, dout, mbits, g3, w3, x, W, dx, part,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((C::NWR + C::NWD) * 64), lds, st, dout, mbits, g3, w3, x, x_map, W, dx, part,
                      pl->poff, pl->cnt, pl->pinfo, pl->ell, pl->prow_off, pl->prow_gid, pl->prow_ptr, pl->pcol, pl->pval, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;

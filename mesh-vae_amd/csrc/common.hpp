@@ -131,7 +131,8 @@ struct DebugCfg {
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
-  int patch_flush_first = 0;   // 1: the step forks the weight-gradient items queued so far BEFORE a patch backward launch
+  int patch_flush_first = 1;   // the step forks the weight-gradient items queued so far (the final layer's) BEFORE a patch backward
+                               // launch, so that they run beside it (MEASURED: 458 against 485 us per step; 0: behind it)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
 };
 DebugCfg& dbg();
@@ -297,10 +298,12 @@ constexpr size_t kLdsWpackBytes = 64 * 1024;
 bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K);
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
-                     uint8_t* bits, int B, int N, int K, int act);
+                     uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map = nullptr /* ConvIO::x_map */,
+                     int x_bs = 0);
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
-                     float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K);
+                     float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K,
+                     const int32_t* x_map = nullptr /* ConvIO::x_map: strided layer input (the dW operand) */, int x_bs = 0);
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,

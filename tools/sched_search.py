@@ -15,6 +15,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITEMS = ["final", "dec3", "dec2", "dec1", "dec0", "enc3", "enc2", "enc1"]
+if os.environ.get("SCHED_NO_DEC3"):      # a level with a vertex-patch plan: dec3 is not a lane item (csrc/cheb_patch.hip)
+    ITEMS = ["final", "dec2", "dec1", "dec0", "enc3", "enc2", "enc1", "-"]
 
 
 def encode(cfg):
@@ -52,6 +54,8 @@ def main():
     args = ap.parse_args()
     # the built-in schedule in this encoding: dec3 (the 5k level) and enc3 on the dense lane; final, dec3, dec1, enc3 wait one fork
     cur = [(0, 1), (1, 1), (0, 0), (0, 1), (0, 0), (1, 1), (0, 0), (0, 0)]
+    if os.environ.get("SCHED_NO_DEC3"):
+        cur = [(0, 0), (0, 0), (0, 1), (0, 0), (1, 1), (0, 0), (0, 0), (0, 0)]
     if args.start:
         lane, hold = (int(v) for v in args.start.split(","))
         cur = [((lane >> k) & 1, (hold >> (2 * k)) & 3) for k in range(8)]
