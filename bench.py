@@ -125,11 +125,47 @@ def matching_profile(config="train5k", dtype="f32"):
     return None, {}, {}
 
 
+def patch_plan_of(lap):
+    """The mvh_patch_plan_t a Laplacian operator (or a CsrStruct pair standing in for one) carries, or None."""
+    import ctypes
+    from meshvae_hip import PatchPlanStruct, lib
+    ptr = lap.fwd.struct.patch
+    if not ptr or lib().mvh_debug_get(b"no_patch"):
+        return None
+    return ctypes.cast(ptr, ctypes.POINTER(PatchPlanStruct)).contents
+
+
+class _LapWithPlan:
+    """The step engine's view of a level: the Laplacian's descriptors with the plan that carries the pooling rows of the
+    level's un-pooling operator (engine.NativeStep) -- the kernel instance the TRAIN STEP launches, for the isolated timing."""
+
+    class _Side:
+        def __init__(self, struct, ell_pairs):
+            import ctypes
+            self.struct, self.ell_pairs, self.ref = struct, ell_pairs, ctypes.byref(struct)
+
+    def __init__(self, lap, plan_struct):
+        import ctypes
+        from meshvae_hip import CsrStruct
+        f, b = CsrStruct.from_buffer_copy(lap.fwd.struct), CsrStruct.from_buffer_copy(lap.bwd.struct)
+        f.patch = b.patch = ctypes.addressof(plan_struct)
+        self.fwd, self.bwd = self._Side(f, lap.fwd.ell_pairs), self._Side(b, lap.bwd.ell_pairs)
+
+
 def lds_kernel_name(kind, lap, N, Cin, Cout, half=False):
     """Template instance the launchers of csrc/cheb_lds.hip / cheb_dw_lds.hip (bf16 rows at the 5k level: cheb_l0h.hip /
     cheb_dw_l0h.hip) pick for a layer (mirrors try_cheb_lds / try_cheb_dw_lds), or None when the layer takes another
     path (split path, stack pipeline)."""
     pw = 8 if lap.fwd.ell_pairs > 4 else 4
+    pp = patch_plan_of(lap)
+    if pp is not None and not half and Cin == 16 and Cout == 16 and kind in ("fwd", "dX+dW"):
+        # vertex-patch kernels (csrc/cheb_patch.hip: FwdCfg / BwdCfg; the SU variant needs that many core tiles per wave)
+        tiles = pp.min_core // 16
+        if kind == "fwd":
+            return f"k_patch_fwd<1024,7,6,{4 if tiles // 16 >= 4 else 0}>"
+        return f"k_patch_bwd<8,8,14,11,40,{10 if tiles // 8 >= 10 else 0}>"
+    if kind == "dX+dW":
+        return None                                                      # (only the patch kernels fuse the two gradients)
     if half and Cin == 16 and Cout == 16 and 2048 < N + 1 <= 5120 and lap.fwd.ell_pairs <= 4 and \
             not (0 < lap.fwd.struct.n_active and 4 * lap.fwd.struct.n_active <= N):
         return "k_cheb_dw_l0h" if kind == "dW" else f"k_cheb_l0h<{'true' if kind == 'dX' else 'false'}>"
@@ -188,8 +224,16 @@ def conv_ops(net, B, dev, dtype="f32"):
     ws_b = max(max(L.mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), L.mvh_cheb_conv_bwd_ws_bytes(B, N, Cin, Cout, K))
                for _, _, N, Cin, Cout, K, _, _ in layers)
     ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)   # one scratch buffer: the ops run one after the other
+    keep_plans = []
     for label, lap, N, Cin, Cout, K, relu, has_dx in layers:
         half = dtype == "bf16" and Cin % 4 == 0 and Cout % 4 == 0
+        if label.startswith("dec") and not half and Cin == 16 and Cout == 16 and patch_plan_of(lap) is not None:
+            from meshvae_hip import topology
+            lvl = [i for i in range(n) if net._lap[i] is lap][0]
+            got = topology.patch_plan(lap, int(K) - 1, net._up[lvl])
+            if got is not None:
+                keep_plans.append(got)
+                lap = _LapWithPlan(lap, got[0])
         td = torch.bfloat16 if half else torch.float32
         esize = 2 if half else 4
         x = torch.randn(B, N, Cin, device=dev).to(td)
@@ -242,6 +286,11 @@ def conv_ops(net, B, dev, dtype="f32"):
         desc = f"{label} N={N} {Cin}->{Cout} K={K}" + (" bf16" if half else "")
         ops.append(dict(op=f"conv fwd {desc}", kernel=lds_kernel_name("fwd", lap, N, Cin, Cout, half), fn=fwd,
                         bytes=pin + pout + (B * N * (Cout // 4) if (use_signs or (half and relu)) else 0), keep=keep))
+        if lds_kernel_name("dX+dW", lap, N, Cin, Cout, half) is not None:
+            # vertex-patch level: both gradients come out of ONE launch (minimum traffic: x, dout and the sign bytes read once, dx written)
+            ops.append(dict(op=f"conv dX+dW {desc}", kernel=lds_kernel_name("dX+dW", lap, N, Cin, Cout, half),
+                            fn=lambda bwd=bwd: bwd(True, True), bytes=2 * pin + pout + sb, keep=keep + (keep_plans,)))
+            continue
         if has_dx:
             ops.append(dict(op=f"conv dX {desc}", kernel=lds_kernel_name("dX", lap, N, Cin, Cout, half),
                             fn=lambda bwd=bwd: bwd(True, False), bytes=pout + sb + pin, keep=keep))
@@ -276,7 +325,7 @@ def step_launches(kernel, B, config, dtype):
     return 1
 
 
-def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "dX", "dW")):
+def kernel_roofline(net, B, dev, config="train5k", dtype="f32", kinds=("fwd", "dX", "dW", "dX+dW")):
     """The `roofline` object of the bench line, for the conv launch that costs most.
 
     Two figures, both reproducible from what the line and profiles/ carry:
