@@ -40,6 +40,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # single-process runs only (the launcher serves variants.reference_loop; a multi-rank line never runs it)
 if os.environ.get("WORLD_SIZE", "1") in ("", "1"):
     os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
+    os.environ.setdefault("MESHVAE_ASYNC", "1")          # (opt-in of the module path)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

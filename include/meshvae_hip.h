@@ -460,6 +460,10 @@ int mvh_launcher_supported(void);
 int mvh_launcher_create(mvh_launcher_t** out);
 int mvh_launcher_sync(mvh_launcher_t* launcher);
 int mvh_launcher_destroy(mvh_launcher_t* launcher);
+/* Test aid (no reference counterpart): queue a job that does no work and, on the worker thread, mode 0 succeeds, 1 throws a C++
+ * exception, 2 returns an error code -- in every case its ticket is written (nothing stays blocked on user_stream) and the failure
+ * is reported by the next launcher call / mvh_launcher_sync. */
+int mvh_launcher_test_job(mvh_launcher_t* launcher, mvh_stream_t user_stream, int32_t mode);
 int mvh_vae_forward_async(mvh_launcher_t* launcher, mvh_stream_t user_stream, const mvh_vae_desc_t* desc,
                           const float* const* params, const float* x, const float* y, const void* x_gt, int32_t gt_f64,
                           const float* eps, const float* drop_u, int32_t B, float log_sigma, void* loss, int64_t* correct,

@@ -353,4 +353,8 @@ int latent_bwd_wgrad(hipStream_t st, const float* h, const float* y, const float
                      float* dWc, float* dbc, float* dWm, float* dbm, float* dWv, float* dbv, int B, int H, int C,
                      int Z);
 
+// the argument checks of mvh_vae_forward / mvh_vae_backward that do not touch the device (descriptor, batch, workspace size):
+// the asynchronous entries run them on the caller's thread before they queue the job (csrc/launcher.hip)
+int vae_step_precheck(const mvh_vae_desc_t* d, int B, const void* ws, size_t ws_bytes);
+
 }  // namespace mvh

@@ -16,15 +16,23 @@
 // it before the job's first launch.  Every async call thus leaves the caller's stream ordered behind the job: later
 // work on that stream -- the consumer of an output, the next allocation that reuses a freed input -- sees the job done.
 //
-// The one way this could hang is S sharing a hardware queue with the caller's stream (S's packets would sit behind the
-// blocked wait).  The runtime pools hardware queues per PRIORITY: S is created with the highest stream priority and
-// so never shares a queue with a default-priority stream of the application.  The value is ALWAYS written, whatever the
-// job returned; the first error of a job is kept and returned by the next call on the launcher.
+// The one way this could hang is a stream the JOB uses sharing a hardware queue with the caller's stream (its packets
+// would sit behind the blocked wait).  The runtime pools hardware queues per PRIORITY: S is created with the highest
+// stream priority, and a step launched on a highest-priority stream forks its weight-gradient work onto lanes of that
+// same priority (csrc/vae_step.hip, lanes_for), so nothing of a job ever queues behind a default-priority stream of the
+// application -- whatever GPU_MAX_HW_QUEUES is and however many streams the application has (test:
+// tests/test_gpu_engine.py::test_async_launcher_with_two_hardware_queues_and_many_streams).  Streams of one pool may share a
+// queue among themselves: packets then run in the host's submission order, in which every wait names earlier work.
+// The value is ALWAYS written, whatever the job returned or threw; the first error of a job is kept and returned by the
+// next call on the launcher (or by mvh_launcher_sync / at destruction).  Arguments are validated on the CALLER's thread
+// before anything is queued, so a bad call fails synchronously like the plain entry points.
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,7 +45,7 @@ struct mvh_launcher {
   uint64_t* flag = nullptr;      // hipMallocSignalMemory: the ticket of the last job whose work S has finished
   uint64_t ticket = 0;           // caller side: last ticket handed out
   hipEvent_t ev[64];
-  struct Job { uint64_t ticket; hipEvent_t ev; std::function<int(hipStream_t)> fn; };
+  struct Job { uint64_t ticket; hipEvent_t ev; std::function<int(hipStream_t)> fn; int kind; };
   std::mutex mu;
   std::condition_variable cv_job, cv_space;
   std::deque<Job> q;
@@ -50,40 +58,62 @@ struct mvh_launcher {
   double t_fn = 0, t_wr = 0;
   long n_tr = 0;
   bool high_prio = true;
-  int spin_us = 400;
+  // The worker polls for the next job for a short while before it sleeps (a futex wake-up costs 30-60 us) -- but only where a
+  // job usually follows soon: after a forward comes its backward (~0.25 ms), after a backward the caller's optimizer
+  // (0.3-0.5 ms of Python) -- so the poll is ADAPTIVE: the idle gap that followed each kind of job is tracked (running
+  // mean) and the worker polls at most 1.5 x that, never more than spin_us, and not at all when the gap is longer.
+  int spin_us = 300;
+  double gap_us[2] = {0.0, 1e9};     // [kind]: running mean of the idle time after a job of that kind (0 forward, 1 backward)
+  std::atomic<bool> alive{false};
   static constexpr size_t kDepth = 4;   // jobs queued on the host side (a step is two; the binding keeps the tensors of the last 6 calls)
 
   void run() {
     (void)hipSetDevice(dev);
+    alive.store(true, std::memory_order_release);
     uint64_t seen = 0;
+    int last_kind = 1;
     for (;;) {
       Job j;
       {
-        // a step hands over two jobs ~0.3 ms apart: poll briefly before sleeping (a futex wake-up costs 30-60 us)
         const auto t0 = std::chrono::steady_clock::now();
-        while (pushed.load(std::memory_order_acquire) == seen &&
-               std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us)) {
+        const double budget = std::min((double)spin_us, 1.5 * gap_us[last_kind]);
+        if (gap_us[last_kind] <= (double)spin_us) {
+          while (pushed.load(std::memory_order_acquire) == seen &&
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < budget) {
 #if defined(__x86_64__)
-          __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+          }
         }
         std::unique_lock<std::mutex> lk(mu);
         cv_job.wait(lk, [&] { return stop || !q.empty(); });
-        if (q.empty()) return;
+        if (q.empty()) break;
+        const double gap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        gap_us[last_kind] = gap_us[last_kind] > 1e8 ? gap : 0.75 * gap_us[last_kind] + 0.25 * std::min(gap, 1e5);
         j = std::move(q.front());
         q.pop_front();
         ++seen;
         busy = true;
       }
       cv_space.notify_all();
+      last_kind = j.kind & 1;
       int rc = MVH_OK;
       std::string msg;
       const auto tj0 = std::chrono::steady_clock::now();
       hipError_t e = hipStreamWaitEvent(S, j.ev, 0);
       if (e != hipSuccess) { rc = MVH_ERR_HIP; msg = std::string("launcher: hipStreamWaitEvent failed: ") + hipGetErrorString(e); }
       if (rc == MVH_OK) {
-        rc = j.fn(S);
-        if (rc != MVH_OK) msg = mvh::last_error_buf();   // (thread-local: this thread's message)
+        // whatever the job does -- return an error, throw -- its ticket is written below: the caller's stream waits for it
+        try {
+          rc = j.fn(S);
+          if (rc != MVH_OK) msg = mvh::last_error_buf();   // (thread-local: this thread's message)
+        } catch (const std::exception& ex) {
+          rc = MVH_ERR_INVALID;
+          msg = std::string("launcher: the job threw: ") + ex.what();
+        } catch (...) {
+          rc = MVH_ERR_INVALID;
+          msg = "launcher: the job threw an unknown exception";
+        }
       }
       const auto tj1 = std::chrono::steady_clock::now();
       e = hipStreamWriteValue64(S, flag, j.ticket, 0);   // ALWAYS: the caller's stream is waiting for this value
@@ -104,6 +134,8 @@ struct mvh_launcher {
       }
       cv_space.notify_all();
     }
+    alive.store(false, std::memory_order_release);
+    cv_space.notify_all();
   }
 };
 
@@ -118,9 +150,10 @@ static int report_kept(mvh_launcher* L) {
   return fail(rc, "asynchronous job failed: %s", L->errmsg.c_str());
 }
 
-static int submit(mvh_launcher* L, hipStream_t user, std::function<int(hipStream_t)> fn) {
+static int submit(mvh_launcher* L, hipStream_t user, int kind, std::function<int(hipStream_t)> fn) {
   MVH_REQUIRE(L != nullptr, "launcher: null handle");
   if (int rc = report_kept(L)) return rc;
+  MVH_REQUIRE(L->alive.load(std::memory_order_acquire), "launcher: the worker thread is gone (nothing was queued)");
   int dev = -1;
   MVH_HIP(hipGetDevice(&dev));
   MVH_REQUIRE(dev == L->dev, "launcher: created on device %d, called on device %d", L->dev, dev);
@@ -133,7 +166,7 @@ static int submit(mvh_launcher* L, hipStream_t user, std::function<int(hipStream
     hipEvent_t ev = L->ev[t % 64];
     MVH_HIP(hipEventRecord(ev, user));
     L->ticket = t;
-    L->q.push_back(mvh_launcher::Job{t, ev, std::move(fn)});
+    L->q.push_back(mvh_launcher::Job{t, ev, std::move(fn), kind});
   }
   L->pushed.fetch_add(1, std::memory_order_release);
   L->cv_job.notify_one();
@@ -149,11 +182,18 @@ extern "C" int mvh_launcher_supported(void) {
   return can ? 1 : 0;
 }
 
-extern "C" int mvh_launcher_create(mvh_launcher_t** out) {
-  MVH_REQUIRE(out != nullptr, "launcher_create: null argument");
-  *out = nullptr;
-  MVH_REQUIRE(mvh_launcher_supported(), "launcher_create: this device has no hipStreamWaitValue64");
-  mvh_launcher* L = new mvh_launcher();
+static void launcher_free(mvh_launcher* L) {     // (no worker thread running)
+  if (!L) return;
+  (void)hipSetDevice(L->dev);
+  if (L->S) (void)hipStreamSynchronize(L->S);
+  for (auto& e : L->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (L->S) (void)hipStreamDestroy(L->S);
+  if (L->flag) (void)hipFree(L->flag);
+  delete L;
+}
+
+static int launcher_init(mvh_launcher* L) {
   MVH_HIP(hipGetDevice(&L->dev));
   int least = 0, greatest = 0;
   MVH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -165,7 +205,21 @@ extern "C" int mvh_launcher_create(mvh_launcher_t** out) {
   MVH_HIP(hipMemset(L->flag, 0, 8));
   MVH_HIP(hipDeviceSynchronize());
   for (auto& e : L->ev) MVH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+  return MVH_OK;
+}
+
+extern "C" int mvh_launcher_create(mvh_launcher_t** out) {
+  MVH_REQUIRE(out != nullptr, "launcher_create: null argument");
+  *out = nullptr;
+  MVH_REQUIRE(mvh_launcher_supported(), "launcher_create: this device has no hipStreamWaitValue64");
+  mvh_launcher* L = new mvh_launcher();
+  for (auto& e : L->ev) e = nullptr;
+  if (int rc = launcher_init(L)) {     // (whatever was created so far is released: stream, signal memory, events)
+    launcher_free(L);
+    return rc;
+  }
   L->th = std::thread([L] { L->run(); });
+  while (!L->alive.load(std::memory_order_acquire)) std::this_thread::yield();
   *out = L;
   return MVH_OK;
 }
@@ -173,8 +227,13 @@ extern "C" int mvh_launcher_create(mvh_launcher_t** out) {
 extern "C" int mvh_launcher_sync(mvh_launcher_t* L) {
   MVH_REQUIRE(L != nullptr, "launcher_sync: null handle");
   {
+    // (a watchdog, not an unconditional wait: if the worker is gone with jobs still queued, say so instead of hanging)
     std::unique_lock<std::mutex> lk(L->mu);
-    L->cv_space.wait(lk, [&] { return L->q.empty() && !L->busy; });
+    while (!(L->q.empty() && !L->busy)) {
+      if (!L->alive.load(std::memory_order_acquire))
+        return fail(MVH_ERR_INVALID, "launcher_sync: the worker thread is gone with %zu job(s) still queued", L->q.size());
+      L->cv_space.wait_for(lk, std::chrono::milliseconds(50));
+    }
   }
   return report_kept(L);
 }
@@ -188,13 +247,17 @@ extern "C" int mvh_launcher_destroy(mvh_launcher_t* L) {
   L->pushed.fetch_add(1, std::memory_order_release);
   L->cv_job.notify_all();
   if (L->th.joinable()) L->th.join();
-  (void)hipSetDevice(L->dev);
-  (void)hipStreamSynchronize(L->S);
-  for (auto& e : L->ev) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(L->S);
-  (void)hipFree(L->flag);
-  delete L;
+  launcher_free(L);
   return MVH_OK;
+}
+
+// test aid (tests/test_gpu_engine.py): a job that throws / returns an error on the worker -- the ticket must still be written
+extern "C" int mvh_launcher_test_job(mvh_launcher_t* L, mvh_stream_t user_stream, int32_t mode) {
+  return submit(L, (hipStream_t)user_stream, 0, [mode](hipStream_t) -> int {
+    if (mode == 1) throw std::runtime_error("test job: deliberate exception");
+    if (mode == 2) return fail(MVH_ERR_INVALID, "test job: deliberate error code");
+    return MVH_OK;
+  });
 }
 
 extern "C" int mvh_vae_forward_async(mvh_launcher_t* L, mvh_stream_t user_stream, const mvh_vae_desc_t* desc,
@@ -203,11 +266,14 @@ extern "C" int mvh_vae_forward_async(mvh_launcher_t* L, mvh_stream_t user_stream
                                      void* loss, int64_t* correct, float* recon, float* kld, void* rec, float* z,
                                      float* y_hat, float* mu, float* logvar, void* ws, size_t ws_bytes) {
   MVH_REQUIRE(desc && params, "vae_forward_async: null descriptor / parameter table");
+  // (validated HERE, on the caller's thread: a bad call fails like the plain entry point, not on a later launcher call)
+  MVH_REQUIRE(x && y && x_gt && loss && correct && recon && kld && rec && z && y_hat && mu && logvar, "vae_forward_async: null tensor");
+  if (int rc = vae_step_precheck(desc, B, ws, ws_bytes)) return rc;
   const int np = mvh_vae_param_count(desc);
   // the caller may reuse its descriptor and pointer table as soon as this returns: the job owns copies
   auto d = std::make_shared<mvh_vae_desc_t>(*desc);
   auto P = std::make_shared<std::vector<const float*>>(params, params + np);
-  return submit(L, (hipStream_t)user_stream, [=](hipStream_t S) {
+  return submit(L, (hipStream_t)user_stream, 0, [=](hipStream_t S) {
     return mvh_vae_forward((mvh_stream_t)S, d.get(), P->data(), x, y, x_gt, gt_f64, eps, drop_u, B, log_sigma, loss, correct,
                            recon, kld, rec, z, y_hat, mu, logvar, ws, ws_bytes);
   });
@@ -219,11 +285,13 @@ extern "C" int mvh_vae_backward_async(mvh_launcher_t* L, mvh_stream_t user_strea
                                       float log_sigma, const void* d_loss, const float* recon, const float* y_hat,
                                       const float* mu, const float* logvar, void* ws, size_t ws_bytes) {
   MVH_REQUIRE(desc && params && grads, "vae_backward_async: null descriptor / pointer table");
+  MVH_REQUIRE(x && y && x_gt && recon && y_hat && mu && logvar, "vae_backward_async: null tensor");
+  if (int rc = vae_step_precheck(desc, B, ws, ws_bytes)) return rc;
   const int np = mvh_vae_param_count(desc);
   auto d = std::make_shared<mvh_vae_desc_t>(*desc);
   auto P = std::make_shared<std::vector<const float*>>(params, params + np);
   auto G = std::make_shared<std::vector<float*>>(grads, grads + np);
-  return submit(L, (hipStream_t)user_stream, [=](hipStream_t S) {
+  return submit(L, (hipStream_t)user_stream, 1, [=](hipStream_t S) {
     return mvh_vae_backward((mvh_stream_t)S, d.get(), P->data(), G->data(), x, y, x_gt, gt_f64, eps, drop_u, B, log_sigma,
                             d_loss, recon, y_hat, mu, logvar, ws, ws_bytes, nullptr);
   });

@@ -156,6 +156,7 @@ struct ParamIdx {
 struct SideStream {
   hipStream_t stream = nullptr;
   hipStream_t dense = nullptr;  // second lane: weight gradients of the dense layers + latent heads
+  hipStream_t hstream = nullptr, hdense = nullptr;   // the same two lanes at the HIGHEST stream priority (lanes_for)
   hipEvent_t ev[64];
   int n_ev = 0;
   int next_ev = 0;
@@ -217,6 +218,35 @@ static SideStream* side_for_device() {
     s.n_ev = 64;
   }
   return &s;
+}
+
+// The two weight-gradient lanes for a step whose main chain runs on `main`.  A caller on a HIGHEST-priority stream -- the
+// asynchronous launcher's (csrc/launcher.hip) -- gets lanes of that same priority: the runtime pools hardware queues per
+// priority, and the launcher's caller leaves a blocked hipStreamWaitValue64 on ITS (default-priority) stream until the job is
+// done -- a default-priority lane that happened to share that stream's hardware queue (few queues, many application
+// streams) would sit behind the blocked wait while the job waits for the lane: a deadlock.  Lanes of the launcher's own
+// pool can only share queues with the launcher's stream, in host submission order.  (caller holds the device's LaneLock)
+static int lanes_for(SideStream* s, hipStream_t main, hipStream_t* conv, hipStream_t* dense) {
+  *conv = s->stream;
+  *dense = s->dense;
+  int lo = 0, hi = 0, pr = 0;
+  if (!main || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) return MVH_OK;
+  if (hipStreamGetPriority(main, &pr) != hipSuccess || pr != hi) return MVH_OK;
+  if (!s->hstream) {
+    MVH_HIP(hipStreamCreateWithPriority(&s->hstream, hipStreamNonBlocking, hi));
+    MVH_HIP(hipStreamCreateWithPriority(&s->hdense, hipStreamNonBlocking, hi));
+  }
+  *conv = s->hstream;
+  *dense = s->hdense;
+  return MVH_OK;
+}
+
+int vae_step_precheck(const mvh_vae_desc_t* d, int B, const void* ws, size_t ws_bytes) {
+  StepPlan p;
+  if (int rc = build_plan(d, B, p)) return rc;
+  MVH_REQUIRE(B > 0, "vae step: empty batch");
+  MVH_REQUIRE(ws && ws_bytes >= p.total, "vae step: workspace too small (%zu < %zu)", ws_bytes, p.total);
+  return MVH_OK;
 }
 
 }  // namespace mvh
@@ -452,7 +482,9 @@ extern "C" int mvh_vae_backward_prefetch(mvh_stream_t stream, const mvh_vae_desc
   const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
                           d->down[0].n_rows == p.Nn[1] && !dbg().no_tstack && !dbg().no_prefetch;
   hipStream_t main = (hipStream_t)stream;
-  hipStream_t sstream = side_stream ? (hipStream_t)side_stream : side->stream;
+  hipStream_t lane_conv = nullptr, lane_dense = nullptr;
+  TRY(lanes_for(side, main, &lane_conv, &lane_dense));
+  hipStream_t sstream = side_stream ? (hipStream_t)side_stream : lane_conv;
   if (!use_tstack || dbg().no_side || sstream == main) return MVH_OK;   // nothing to run ahead: the backward does it all
   side->tstack_x = x; side->tstack_ws = ws; side->tstack_stream = sstream; side->tstack_armed = true;
   return MVH_OK;
@@ -490,10 +522,12 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward: could not create the side stream");
-  hipStream_t sstream = side_stream ? (hipStream_t)side_stream : side->stream;
+  hipStream_t lane_conv = nullptr, lane_dense = nullptr;
+  TRY(lanes_for(side, main, &lane_conv, &lane_dense));
+  hipStream_t sstream = side_stream ? (hipStream_t)side_stream : lane_conv;
   if (dbg().no_side) sstream = main;  // debugging aid: weight gradients on the main chain
   // dense-layer weight gradients: their own lane (they would delay the conv dW chain on `sstream`)
-  hipStream_t dstream = (sstream == main) ? main : (side_stream ? sstream : side->dense);
+  hipStream_t dstream = (sstream == main) ? main : (side_stream ? sstream : lane_dense);
   void* sm = (char*)ws + p.scratch_main;
   void* ss = (char*)ws + p.scratch_side;
   // debug switch dw_lane2: the small levels' conv weight gradients alternate between the conv lane and the dense lane

@@ -7,35 +7,20 @@ tensor, the call raises.
 import ctypes
 import os
 
-# More hardware queues than the HIP default of 4: the native step uses three streams and a process group adds
-# RCCL's; once streams share a queue the weight-gradient lanes serialise behind the main chain (+30 % step time,
-# tools/dist_overhead2.sh).  Only effective if the HIP runtime has not been initialised yet (import this
-# package, or set the variable, before the first torch.cuda call).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-
-def _hip_started():
-    import sys
-    t = sys.modules.get("torch")
-    try:
-        return bool(t is not None and t.cuda.is_initialized())
-    except Exception:
-        return False
-
-
-# The asynchronous launcher (csrc/launcher.hip) leaves hipStreamWaitValue64 waits on the caller's stream.  By default the
-# runtime executes such a wait as a SHADER that spins on a compute unit for as long as the job runs -- measured: the step's
-# kernels then take 0.75 instead of 0.49 ms (profiles/r04_async_probe.txt) --; GPU_STREAMOPS_CP_WAIT=1 makes the command
-# processor wait instead (0.55 ms).  Like the queue count it is read when the HIP runtime initialises, so the launcher is
-# only used when the variable was in place by then: set by the caller, or set here before the first torch.cuda call.
-# Single-process jobs only: a rank of a data-parallel job (WORLD_SIZE > 1) runs engine.TrainStep, which does not use the
-# launcher, and the collective library's own stream memory operations have never been exercised with this switch.
-_cp_preset = os.environ.get("GPU_STREAMOPS_CP_WAIT")
-_started = _hip_started()
-_single = os.environ.get("WORLD_SIZE", "1") in ("", "1")
-if _single:
-    os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")
-CP_WAIT = (_cp_preset == "1") or (_cp_preset is None and not _started and _single)
+# Importing this package changes NOTHING in the process environment.  Two runtime settings matter to it, both read by the
+# HIP runtime when IT initialises (the first hipGetDeviceCount: torch.cuda.is_available() already counts), so both belong to
+# whoever starts the process:
+#   * GPU_STREAMOPS_CP_WAIT=1 -- needed by the ASYNCHRONOUS LAUNCHER (csrc/launcher.hip), an opt-in of the module path
+#     (MESHVAE_ASYNC=1): its hipStreamWaitValue64 waits then run on the command processor; by default the runtime executes
+#     such a wait as a SHADER that spins on a compute unit for as long as the job runs (the step's kernels: 0.75 instead of
+#     0.49 ms, profiles/r04_async_probe.txt).  The launcher is used only when the variable was PRESET to 1 (this package
+#     cannot tell whether a value set later was still in time: torch.cuda.is_initialized() stays False after is_available()).
+#   * GPU_MAX_HW_QUEUES -- left at the runtime's default (4): the train step keeps three queues busy (caller's stream + two
+#     weight-gradient lanes) and a data-parallel rank's collective stream is the fourth (profiles/r05_fourth_queue.txt).
+# MESHVAE_ASYNC: "" / "0" = never use the launcher (default); "1" = use it when GPU_STREAMOPS_CP_WAIT=1 is preset;
+# "force" = use it regardless (A/B tooling: measures the spinning-shader case).
+ASYNC_MODE = os.environ.get("MESHVAE_ASYNC", "0")
+CP_WAIT = os.environ.get("GPU_STREAMOPS_CP_WAIT") == "1"
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MESHVAE_LIB lets a benchmark A/B two builds of the library in one process-per-run session
@@ -144,6 +129,7 @@ SIGNATURES = {
     "mvh_launcher_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "mvh_launcher_sync": (ctypes.c_int, [_P]),
     "mvh_launcher_destroy": (ctypes.c_int, [_P]),
+    "mvh_launcher_test_job": (ctypes.c_int, [_P, _P, _I]),
     "mvh_vae_forward_async": (ctypes.c_int, [_P, _P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 9 + [_P, _Z]),
     "mvh_vae_backward_async": (ctypes.c_int, [_P, _P, ctypes.POINTER(VaeDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _F] + [_P] * 5 + [_P, _Z]),
     "mvh_vae_loss_bwd": (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 4),
@@ -189,8 +175,8 @@ def launcher(device_index):
     if device_index in _launchers:
         return _launchers[device_index]
     handle = None
-    mode = os.environ.get("MESHVAE_ASYNC", "1")            # "0": never; "force": even without the command-processor wait
-    if mode != "0" and (CP_WAIT or mode == "force"):
+    mode = ASYNC_MODE                                       # opt-in: see the top of this file
+    if (mode == "1" and CP_WAIT and os.environ.get("WORLD_SIZE", "1") in ("", "1")) or mode == "force":
         import torch
         with torch.cuda.device(device_index):
             if lib().mvh_launcher_supported():
@@ -211,6 +197,12 @@ def _destroy_launchers():
         return
     for k, h in list(_launchers.items()):
         if h is not None:
+            # a job that failed AFTER the last launcher call of the script has told nobody yet: say so now (its outputs --
+            # a last eval batch, a single inference call -- are uninitialised memory)
+            if lib().mvh_launcher_sync(h) != 0:
+                import sys
+                print(f"meshvae_hip: an asynchronous job on device {k} failed and was never reported: "
+                      f"{lib().mvh_last_error().decode()}", file=sys.stderr)
             lib().mvh_launcher_destroy(h)
         _launchers[k] = None
 

@@ -215,6 +215,15 @@ class TrainStep:
         self.y = torch.zeros(batch, net.num_class, dtype=torch.float32, device=self.dev)
         self.eps = torch.zeros(batch, net.z, device=self.dev)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # Hardware-queue budget (profiles/r05_fourth_queue.txt): the step keeps three queues busy (caller's stream + two
+        # weight-gradient lanes) -- fine under the runtime's default of 4; a process group adds the collective library's
+        # streams, and with 4 queues the lanes then share the main chain's (0.59-0.61 instead of 0.47 ms per step with a
+        # 1-rank RCCL group).  The variable is read when the HIP runtime starts, so it is the launching script's to set.
+        if (self.world > 1 or rehearse_allreduce) and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+            import warnings
+            warnings.warn("meshvae_hip.TrainStep with a process group: set GPU_MAX_HW_QUEUES=8 in the environment of every "
+                          "rank before the first torch.cuda call (the default of 4 hardware queues makes the step's "
+                          "weight-gradient lanes share the main chain's queue: ~30 % slower steps)", RuntimeWarning)
         self.use_graph = use_graph
         self.graph_fb = self.graph_opt = None
         self._out = None

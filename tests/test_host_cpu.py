@@ -265,23 +265,25 @@ def test_list_meshes_and_obj_round_trip(tmp_path, capsys):
     assert np.array_equal(v2, v) and np.array_equal(f2, f)
 
 
-def test_cp_wait_switch_is_set_only_where_the_launcher_may_run():
-    """meshvae_hip sets GPU_STREAMOPS_CP_WAIT=1 at import (the asynchronous launcher's value waits on the command processor
-    instead of a spinning shader) -- in single-process jobs only, never over a caller's own setting, and it reports through
-    meshvae_hip.CP_WAIT whether the launcher may be used.  Child processes: the decision is taken at import time."""
+def test_import_changes_nothing_and_the_launcher_is_an_opt_in():
+    """importing meshvae_hip leaves the process environment alone -- GPU_STREAMOPS_CP_WAIT, GPU_MAX_HW_QUEUES
+    and every other variable belong to whoever starts the process -- and the asynchronous launcher is used only when the
+    caller asked for it (MESHVAE_ASYNC=1) AND preset GPU_STREAMOPS_CP_WAIT=1 (its value waits then run on the command
+    processor instead of a spinning shader); a rank of a data-parallel job never uses it.  Child processes: the decision
+    is taken at import time."""
     import subprocess
     import sys
-    code = ("import os, sys; sys.path.insert(0, %r); import meshvae_hip; "
-            "print(os.environ.get('GPU_STREAMOPS_CP_WAIT'), meshvae_hip.CP_WAIT)" % PKG)
+    code = ("import os, sys; before = dict(os.environ); sys.path.insert(0, %r); import meshvae_hip; "
+            "print(dict(os.environ) == before, meshvae_hip.CP_WAIT, meshvae_hip.ASYNC_MODE)" % PKG)
 
     def run(**env):
-        e = {k: v for k, v in os.environ.items() if k not in ("GPU_STREAMOPS_CP_WAIT", "WORLD_SIZE")}
+        e = {k: v for k, v in os.environ.items() if k not in ("GPU_STREAMOPS_CP_WAIT", "WORLD_SIZE", "MESHVAE_ASYNC", "GPU_MAX_HW_QUEUES")}
         e.update(env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr[-500:]
         return out.stdout.split()
-    assert run() == ["1", "True"]                                   # nothing set: switched on, launcher allowed
-    assert run(GPU_STREAMOPS_CP_WAIT="0") == ["0", "False"]         # the caller's choice stands
-    assert run(GPU_STREAMOPS_CP_WAIT="1") == ["1", "True"]
-    assert run(WORLD_SIZE="8") == ["None", "False"]                 # a rank of a data-parallel job: untouched
-    assert run(WORLD_SIZE="1") == ["1", "True"]
+    assert run() == ["True", "False", "0"]                                          # import alone: nothing set, no launcher
+    assert run(MESHVAE_ASYNC="1") == ["True", "False", "1"]                         # asked for, but no command-processor wait preset
+    assert run(MESHVAE_ASYNC="1", GPU_STREAMOPS_CP_WAIT="1") == ["True", "True", "1"]
+    assert run(GPU_STREAMOPS_CP_WAIT="1") == ["True", "True", "0"]                  # preset but not asked for: no launcher
+    assert run(GPU_STREAMOPS_CP_WAIT="0", MESHVAE_ASYNC="1") == ["True", "False", "1"]
