@@ -582,23 +582,44 @@ class RefBatch:
         self.x, self.num_graphs, self.edge_index = x.reshape(-1, x.shape[-1]), x.shape[0], None
 
 
-def reference_loop_variant(dev, B, steps, warmup, prewarm):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_loop_variant(dev, B, steps, warmup, prewarm, grad_mode="autograd"):
     """The reference's OWN call sequence around the drop-in modules, timed with the headline's protocol -- what an unchanged
     main.py gets (main.py:74-81 and :251): optimizer.zero_grad() -> model(data, x_gt, sex_hot, m_type="train") ->
     loss.backward() -> torch.optim.Adam(net.parameters(), lr, weight_decay=5e-4).step(); fp64 x_gt and int64 one-hot labels
     as main.py:69-71 hand them over; no engine.TrainStep, no fused optimizer."""
     net = build_model(dev).train()
+    if grad_mode != "autograd":
+        net.grad_mode = grad_mode            # the one-line opt-in of models/cheb_VAE.py (gradients assigned, not accumulated)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
     x = torch.randn(B, net.num_nodes[0], 3, generator=torch.Generator().manual_seed(0)).to(dev)
     x_gt = x.double()
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
     data = RefBatch(x)
+    phase = [0.0] * 4
 
-    def step():
+    def step(acc=False):
+        t0 = time.perf_counter()
         opt.zero_grad()
+        t1 = time.perf_counter()
         loss, correct, out, z, y_hat = net(data, x_gt, y, m_type="train")
+        t2 = time.perf_counter()
         loss.backward()
+        t3 = time.perf_counter()
         opt.step()
+        if acc:
+            t4 = time.perf_counter()
+            for i, v in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                phase[i] += v
         return loss
     for i in range(prewarm + warmup):
         step()
@@ -612,6 +633,11 @@ def reference_loop_variant(dev, B, steps, warmup, prewarm):
     dt = time.perf_counter() - t0
     loss = float(loss.detach())
     assert np.isfinite(loss), "non-finite loss in the reference-loop variant"
+    n_ph = max(20, min(steps, 100))          # host time of each phase (the loop is host-bound), outside the timed region
+    for _ in range(n_ph):
+        step(True)
+    torch.cuda.synchronize(dev)
+    host_us = {k: round(1e6 * v / n_ph, 1) for k, v in zip(("zero_grad", "net()", "backward", "optimizer.step"), phase)}
     import meshvae_hip
     mps = B * steps / dt
     bpm = ALGO_BYTES_PER_MESH[("train5k", "f32")]
@@ -619,7 +645,9 @@ def reference_loop_variant(dev, B, steps, warmup, prewarm):
                         "net(data, x_gt, y, m_type='train') -> loss.backward() -> torch.optim.Adam.step() -> zero_grad()",
             "value": mps, "unit": "meshes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
             "prewarm_steps": prewarm, "dtype": "f32", "final_loss": loss, "optimizer": "torch.optim.Adam (torch default: foreach)",
-            "async_launcher": meshvae_hip.launcher(dev.index) is not None,
+            "async_launcher": meshvae_hip.launcher(dev.index) is not None, "grad_mode": grad_mode,
+            "host_us": host_us, "host_cpu": cpu_model(),
+            "note": "host-bound: the calling thread's time per step is the sum of host_us (it scales with the host CPU, not the GPU)",
             "step_roofline": {"bound": "hbm", "achieved": mps * bpm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": mps * bpm / 1e9 / HBM_PEAK_GBS, "note": f"meshes/s x {bpm / 1e6:.2f} MB/mesh (SURVEY 8(d))"}}
 
@@ -775,6 +803,10 @@ def main():
                 "bf16": timed_variant(dev, "train5k", "bf16", B, args.steps, args.warmup, min(prewarm, 100), args.seed),
                 "hires20k": timed_variant(dev, "hires20k", "f32", B, max(10, args.steps // 2), max(3, args.warmup // 2), 20,
                                           args.seed)}
+            # the same loop with the module's one-line opt-in net.grad_mode = "assign" (models/cheb_VAE.py: gradients
+            # assigned to .grad, not accumulated through 29 AccumulateGrad nodes): reported beside, never instead
+            ra = reference_loop_variant(dev, B, args.steps, args.warmup, min(prewarm, 100), grad_mode="assign")
+            out["variants"]["reference_loop"]["grad_mode_assign"] = {k: ra[k] for k in ("value", "ms_per_step", "host_us", "final_loss")}
             # ... and configs[4] (inference, hipGraph replay): the latencies of `--config infer`
             _, lat, eager, it = infer_latencies(dev, max(20, args.steps), max(3, args.warmup // 2))
             _, lat2, _, _ = infer_latencies(dev, max(20, args.steps), max(3, args.warmup // 2), batched=True)

@@ -18,11 +18,10 @@
 //
 // The one way this could hang is a stream the JOB uses sharing a hardware queue with the caller's stream (its packets
 // would sit behind the blocked wait).  The runtime pools hardware queues per PRIORITY: S is created with the highest
-// stream priority, and a step launched on a highest-priority stream forks its weight-gradient work onto lanes of that
-// same priority (csrc/vae_step.hip, lanes_for), so nothing of a job ever queues behind a default-priority stream of the
-// application -- whatever GPU_MAX_HW_QUEUES is and however many streams the application has (test:
-// tests/test_gpu_engine.py::test_async_launcher_with_two_hardware_queues_and_many_streams).  Streams of one pool may share a
-// queue among themselves: packets then run in the host's submission order, in which every wait names earlier work.
+// stream priority, and a step launched on a highest-priority stream runs its weight-gradient work INLINE on that stream
+// instead of forking it onto the (default-priority) lanes (csrc/vae_step.hip, lanes_for), so nothing of a job ever queues
+// behind a default-priority stream of the application -- whatever GPU_MAX_HW_QUEUES is and however many streams the
+// application has (test: tests/test_gpu_engine.py::test_async_launcher_with_two_hardware_queues_and_many_streams).
 // The value is ALWAYS written, whatever the job returned or threw; the first error of a job is kept and returned by the
 // next call on the launcher (or by mvh_launcher_sync / at destruction).  Arguments are validated on the CALLER's thread
 // before anything is queued, so a bad call fails synchronously like the plain entry points.

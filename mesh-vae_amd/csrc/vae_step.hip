@@ -156,7 +156,6 @@ struct ParamIdx {
 struct SideStream {
   hipStream_t stream = nullptr;
   hipStream_t dense = nullptr;  // second lane: weight gradients of the dense layers + latent heads
-  hipStream_t hstream = nullptr, hdense = nullptr;   // the same two lanes at the HIGHEST stream priority (lanes_for)
   hipEvent_t ev[64];
   int n_ev = 0;
   int next_ev = 0;
@@ -221,23 +220,22 @@ static SideStream* side_for_device() {
 }
 
 // The two weight-gradient lanes for a step whose main chain runs on `main`.  A caller on a HIGHEST-priority stream -- the
-// asynchronous launcher's (csrc/launcher.hip) -- gets lanes of that same priority: the runtime pools hardware queues per
-// priority, and the launcher's caller leaves a blocked hipStreamWaitValue64 on ITS (default-priority) stream until the job is
-// done -- a default-priority lane that happened to share that stream's hardware queue (few queues, many application
-// streams) would sit behind the blocked wait while the job waits for the lane: a deadlock.  Lanes of the launcher's own
-// pool can only share queues with the launcher's stream, in host submission order.  (caller holds the device's LaneLock)
+// asynchronous launcher's (csrc/launcher.hip) -- gets NO lanes: its weight-gradient work runs inline on `main`.  The launcher's
+// caller leaves a blocked hipStreamWaitValue64 on ITS (default-priority) stream until the job is done; a default-priority
+// lane that happened to share that stream's hardware queue (few queues, many application streams) would sit behind the
+// blocked wait while the job waits for the lane: a deadlock.  The runtime pools hardware queues per priority, so only
+// streams of the launcher's own priority are safe -- and lanes of that priority were MEASURED at 2.5 ms per step instead
+// of 0.46 (profiles/r05_ref_loop_probe.txt: the high-priority pool does not run three streams side by side).  Inline, the
+// step's GPU time is ~0.6 ms, below what the host-bound loop the launcher serves needs per step (0.7-0.8 ms).
+// (caller holds the device's LaneLock)
 static int lanes_for(SideStream* s, hipStream_t main, hipStream_t* conv, hipStream_t* dense) {
   *conv = s->stream;
   *dense = s->dense;
   int lo = 0, hi = 0, pr = 0;
   if (!main || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi) return MVH_OK;
   if (hipStreamGetPriority(main, &pr) != hipSuccess || pr != hi) return MVH_OK;
-  if (!s->hstream) {
-    MVH_HIP(hipStreamCreateWithPriority(&s->hstream, hipStreamNonBlocking, hi));
-    MVH_HIP(hipStreamCreateWithPriority(&s->hdense, hipStreamNonBlocking, hi));
-  }
-  *conv = s->hstream;
-  *dense = s->hdense;
+  *conv = main;
+  *dense = main;
   return MVH_OK;
 }
 

@@ -76,6 +76,49 @@ class _FusedModelFn(torch.autograd.Function):
                 *[None if v is None else as_strided(v[0], v[1], v[2]) for v in ent["views"]])
 
 
+class _FusedModelAssignFn(torch.autograd.Function):
+    """net.grad_mode = "assign" (opt-in): the same fused step, but autograd sees ONE differentiable input (a dummy scalar
+    of the module) instead of the 31 parameters, and the backward ASSIGNS every parameter's .grad itself -- views of a
+    flat buffer, two buffers in rotation -- instead of returning 29 gradients to 29 AccumulateGrad nodes (about 100 us
+    of the ~150 us `loss.backward()` costs the calling thread).  What it gives up: gradient ACCUMULATION over several
+    backward calls, parameter hooks, torch.autograd.grad(loss, params), DDP wrappers -- the plain main.py loop
+    (zero_grad -> net() -> backward -> optimizer.step, main.py:74-81) uses none of them."""
+
+    @staticmethod
+    def forward(ctx, ent, lch, x, x_gt, y, eps, drop_u, dummy):
+        step = ent["step"]
+        outs, y_f = ent["alloc"](x, x_gt, y)
+        step.run_forward(x, x_gt, y_f, eps, drop_u, outs, lch)
+        loss, correct, recon, kld, rec, z_, y_hat, mu, logvar = outs
+        ctx.ent, ctx.gen, ctx.lch = ent, ent["gen"], lch
+        ctx.saved = (x, x_gt, y_f, eps, drop_u, recon, y_hat, mu, logvar)
+        ent["keep"].append(ctx.saved + (loss, correct, kld, rec, z_))
+        res = (loss, correct, recon, kld, rec, z_, y_hat)
+        ctx.mark_non_differentiable(*res[1:])
+        ctx.set_materialize_grads(False)
+        return res
+
+    @staticmethod
+    def backward(ctx, d_loss, *_):
+        ent = ctx.ent
+        if ent["gen"] != ctx.gen:
+            raise RuntimeError("cheb_VAE fused forward: backward() must follow its own forward")
+        if d_loss is None:
+            return (None,) * 8
+        x, x_gt, y_f, eps, drop_u, recon, y_hat, mu, logvar = ctx.saved
+        step = ent["step"]
+        d_loss = d_loss.contiguous()
+        slot = ent["assign"][ent["assign_i"]]
+        ent["assign_i"] ^= 1
+        flat, G, grads = slot
+        step.run_backward(x, x_gt, y_f, eps, drop_u, d_loss, recon, y_hat, mu, logvar, G, ctx.lch)
+        ent["keep"].append(ctx.saved + (d_loss,))
+        for p, g in zip(ent["params"], grads):
+            if g is not None:
+                p.grad = g
+        return (None,) * 8
+
+
 class cheb_VAE(torch.nn.Module):
 
     def __init__(self, num_features, config, downsample_matrices, upsample_matrices,
@@ -250,7 +293,16 @@ class cheb_VAE(torch.nn.Module):
             eps = provider(B, self.z, dev) if provider is not None else None
             if eps is None:                # no engine buffer for this batch size: host generator, as the reference (:316)
                 eps = self._host_eps(B, dev)
-        drop_u = torch.rand(B * step.u_cols, device=dev) if (self.training and self.dropout.p > 0.0) else None
+        drop_u = None
+        if self.training and self.dropout.p > 0.0:
+            # the uniforms of U_AHEAD calls from ONE generator launch (as engine.TrainStep does): a call takes its row
+            ring = ent["drop"]
+            if ring["left"] == 0:
+                ring["i"] ^= 1
+                ring["buf"][ring["i"]] = torch.rand(self.U_AHEAD, B * step.u_cols, device=dev)   # (a fresh block: earlier rows may still be in use)
+                ring["left"] = self.U_AHEAD
+            drop_u = ring["buf"][ring["i"]][self.U_AHEAD - ring["left"]]
+            ring["left"] -= 1
         ent["gen"] += 1
         x, x_gt = x.contiguous(), x_gt.contiguous()
         # (inside a stream capture -- TrainStep(native=False, use_graph=True) -- the launches must be recorded by the
@@ -262,7 +314,10 @@ class cheb_VAE(torch.nn.Module):
             ent["keep"].append((x, x_gt, y_f, eps, drop_u) + outs)
             loss, correct, recon, kld, rec, z_, y_hat = outs[:7]
             return loss, correct, recon, [kld, rec, z_], y_hat
-        outs = _FusedModelFn.apply(ent, lch, x, x_gt, y, eps, drop_u, *step.params)
+        if getattr(self, "grad_mode", "autograd") == "assign":
+            outs = _FusedModelAssignFn.apply(ent, lch, x, x_gt, y, eps, drop_u, self._assign_dummy(dev))
+        else:
+            outs = _FusedModelFn.apply(ent, lch, x, x_gt, y, eps, drop_u, *step.params)
         loss, correct, recon, kld, rec, z_, y_hat = outs
         return loss, correct, recon, [kld, rec, z_], y_hat
 
@@ -310,7 +365,16 @@ class cheb_VAE(torch.nn.Module):
                          torch.empty(B, N0, F0, **f32), torch.empty(B, **f32), torch.empty(B, dtype=lt, device=dev),
                          torch.empty(B, Z, **f32), torch.empty(B, C, **f32), torch.empty(B, Z, **f32),
                          torch.empty(B, Z, **f32)), y_f)
+            def assign_slot():
+                """one flat gradient buffer of the "assign" mode with its pointer table and the parameters' views of it"""
+                flat = torch.empty(off, dtype=torch.float32, device=dev)
+                Gs = (ctypes.c_void_p * len(params))()
+                np.frombuffer(Gs, dtype=np.uint64)[:] = np.asarray(offs, dtype=np.uint64) * np.uint64(4) + np.uint64(flat.data_ptr())
+                grads = [None if v is None else flat.as_strided(v[0], v[1], v[2]) for v in views]
+                return flat, Gs, grads
             ent = cache[B_key] = {"step": step, "gen": 0, "numel": off, "views": views, "G": G,
+                                  "params": params, "assign": None, "assign_i": 0, "assign_slot": assign_slot,
+                                  "drop": {"left": 0, "i": 0, "buf": [None, None]},
                                   "G_np": np.frombuffer(G, dtype=np.uint64),
                                   "off_np": np.asarray(offs, dtype=np.uint64) * np.uint64(4), "alloc": alloc,
                                   # the tensors of the last few calls stay referenced: a job handed to the asynchronous
@@ -319,7 +383,17 @@ class cheb_VAE(torch.nn.Module):
                                   "keep": collections.deque(maxlen=6),
                                   "launcher": meshvae_hip.launcher(dev.index) if getattr(self, "async_launch", True) else None}
         ent["step"].refresh_param_pointers()
+        if getattr(self, "grad_mode", "autograd") == "assign" and ent["assign"] is None:
+            ent["assign"] = [ent["assign_slot"](), ent["assign_slot"]()]
         return ent
+
+    U_AHEAD = 16      # calls whose dropout uniforms one generator launch draws (module path; engine.TrainStep has its own)
+
+    def _assign_dummy(self, dev):
+        d = self.__dict__.get("_assign_dummy_t")
+        if d is None or d.device != dev:
+            d = self.__dict__["_assign_dummy_t"] = torch.zeros((), device=dev, requires_grad=True)
+        return d
 
     def _native_ok(self, t):
         """Piecewise inference calls (net.encoder / net.decoder under no_grad) take the native launch sequences."""

@@ -802,8 +802,9 @@ def _ref_model(which, dev, dropout=0.0):
 def test_reference_loop_ends_where_trainstep_ends(which, B):
     """The reference's own loop over the drop-in modules (main.py:74-81,251: zero_grad -> net(data, x_gt, y) ->
     loss.backward() -> torch.optim.Adam.step()) and engine.TrainStep (flat buffers, fused Adam) are the same training:
-    same host noise, three steps, parameters within 1e-6 -- with the asynchronous launcher (the default where the device has
-    hipStreamWaitValue64) and without it; the two module-path runs agree bitwise (the launcher moves launch CALLS only).
+    same host noise, three steps, parameters within 1e-6 -- with the asynchronous launcher (an opt-in, where the device has
+    hipStreamWaitValue64) and without it, with the gradients going through autograd or assigned by the fused backward
+    (net.grad_mode = "assign"); the four module-path runs agree bitwise (launcher and grad mode move host work only).
     The 1e-6 holds for all but a handful of the 5k model's 712 642 parameters: the gradients of the first step ARE bitwise
     equal (same kernels; tools/diag/ref_vs_trainstep.py), the two Adam implementations differ in the last bit of an update,
     and Adam's m / (sqrt(v) + eps) turns that into 1e-6 .. 1e-5 where a later gradient is ~1e-8 (measured: 6 entries of
@@ -825,9 +826,11 @@ def test_reference_loop_ends_where_trainstep_ends(which, B):
         step.step()
     want = {k: v.detach().clone() for k, v in net.state_dict().items()}
     runs = {}
-    for use_async in (True, False):
+    for use_async, grad_mode in ((True, "autograd"), (False, "autograd"), (True, "assign"), (False, "assign")):
         net = _ref_model(which, dev)
         net.async_launch = use_async
+        if grad_mode == "assign":          # the module's opt-in: .grad assigned by the fused backward
+            net.grad_mode = "assign"
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
         torch.manual_seed(5)
         losses = []
@@ -840,13 +843,15 @@ def test_reference_loop_ends_where_trainstep_ends(which, B):
         ent = next(iter(net._fused_cache.values()))
         assert (ent["launcher"] is not None) == (use_async and meshvae_hip.launcher(0) is not None)
         assert net.dec_lin_1.weight.grad is None and net.cheb[0].weight.grad is not None
-        runs[use_async] = ({k: v.detach().clone() for k, v in net.state_dict().items()}, [float(l) for l in losses])
-        for k, v in runs[use_async][0].items():
+        runs[use_async, grad_mode] = ({k: v.detach().clone() for k, v in net.state_dict().items()}, [float(l) for l in losses])
+        for k, v in runs[use_async, grad_mode][0].items():
             dlt = (v - want[k]).abs()
             assert float(dlt.max()) <= 2e-5, (k, float(dlt.max()))
             assert int((dlt > 1e-6).sum()) <= max(0, int(1e-4 * dlt.numel())), (k, int((dlt > 1e-6).sum()))
-    assert runs[True][1] == runs[False][1]
-    assert all(torch.equal(runs[True][0][k], runs[False][0][k]) for k in want)
+    first = runs[True, "autograd"]
+    for key, (sd, ls) in runs.items():      # launcher on / off, gradients through autograd / assigned: the same numbers, bit for bit
+        assert ls == first[1], key
+        assert all(torch.equal(sd[k], first[0][k]) for k in want), key
     if meshvae_hip.launcher(0) is not None:
         meshvae_hip.check(meshvae_hip.lib().mvh_launcher_sync(meshvae_hip.launcher(0)))
 

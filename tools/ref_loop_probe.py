@@ -33,8 +33,11 @@ def main():
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
     d = bench.RefBatch(x) if hasattr(bench, "RefBatch") else type("D", (), dict(x=x.reshape(-1, 3), num_graphs=B,
                                                                                  edge_index=None))()
-    for label, kw in (("foreach (default)", {}), ("fused=True", {"fused": True}), ("foreach=False", {"foreach": False})):
+    for label, kw in (("foreach (default)", {}), ("foreach, grad_mode=assign", {"_assign": True}), ("fused=True", {"fused": True}),
+                      ("fused=True, assign", {"fused": True, "_assign": True})):
         net = bench.build_model(dev).train()
+        if kw.pop("_assign", False):
+            net.grad_mode = "assign"
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4, **kw)
         ph = [0.0] * 4
 
@@ -63,7 +66,7 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / a.steps
         us = [1e6 * v / a.steps for v in ph]
-        print(f"reference loop, Adam {label:18s}: {ms:.4f} ms/step  host us: zero_grad {us[0]:.0f} net() {us[1]:.0f} "
+        print(f"reference loop, Adam {label:26s}: {ms:.4f} ms/step  host us: zero_grad {us[0]:.0f} net() {us[1]:.0f} "
               f"backward {us[2]:.0f} opt.step {us[3]:.0f} (sum {sum(us):.0f})  loss {float(loss):.1f}", flush=True)
     from meshvae_hip.engine import TrainStep
     net = bench.build_model(dev).train()
