@@ -33,7 +33,7 @@ struct DebugKey {
 };
 static const DebugKey kDebugKeys[] = {
     {"force_generic", &DebugCfg::force_generic}, {"l0_wide", &DebugCfg::l0_wide},
-    {"side_prio", &DebugCfg::side_prio},         {"no_side", &DebugCfg::no_side},
+    {"side_prio", &DebugCfg::side_prio},         {"launcher_lanes", &DebugCfg::launcher_lanes},         {"no_side", &DebugCfg::no_side},
     {"no_tstack", &DebugCfg::no_tstack},         {"tail_main", &DebugCfg::tail_main},
     {"fork_batch", &DebugCfg::fork_batch},       {"no_gstack_mfma", &DebugCfg::no_gstack_mfma},
     {"no_dw_mfma", &DebugCfg::no_dw_mfma},       {"no_xcd_remap", &DebugCfg::no_xcd_remap},

@@ -93,6 +93,7 @@ struct DebugCfg {
   int force_generic = 0;   // 1: never take the LDS-resident kernels (general stack pipeline everywhere)
   int l0_wide = 0;         // 1: 512 threads x 10 vertices at the 5k level instead of 1024 x 5
   int side_prio = 0;       // -1 / +1: low / high queue priority for the weight-gradient lanes
+  int launcher_lanes = 0;  // launcher jobs: 0 = gradient work inline on the job's stream, 1 = lowest-priority gradient lanes (2.5 ms/step)
   int no_side = 0;         // 1: weight gradients inline on the main stream
   int no_tstack = 0;       // 1: first-layer dW through the recurrence kernel instead of the saved stack
   int tail_main = 0;       // 1: encoder layer 1's dW runs on the main stream after layer 0's (round 1's choice; since the

@@ -156,6 +156,7 @@ struct ParamIdx {
 struct SideStream {
   hipStream_t stream = nullptr;
   hipStream_t dense = nullptr;  // second lane: weight gradients of the dense layers + latent heads
+  hipStream_t lstream = nullptr, ldense = nullptr;  // the same two lanes at LOWEST queue priority, for the launcher's jobs (lanes_for)
   hipEvent_t ev[64];
   int n_ev = 0;
   int next_ev = 0;
@@ -220,13 +221,15 @@ static SideStream* side_for_device() {
 }
 
 // The two weight-gradient lanes for a step whose main chain runs on `main`.  A caller on a HIGHEST-priority stream -- the
-// asynchronous launcher's (csrc/launcher.hip) -- gets NO lanes: its weight-gradient work runs inline on `main`.  The launcher's
-// caller leaves a blocked hipStreamWaitValue64 on ITS (default-priority) stream until the job is done; a default-priority
-// lane that happened to share that stream's hardware queue (few queues, many application streams) would sit behind the
-// blocked wait while the job waits for the lane: a deadlock.  The runtime pools hardware queues per priority, so only
-// streams of the launcher's own priority are safe -- and lanes of that priority were MEASURED at 2.5 ms per step instead
-// of 0.46 (profiles/r05_ref_loop_probe.txt: the high-priority pool does not run three streams side by side).  Inline, the
-// step's GPU time is ~0.6 ms, below what the host-bound loop the launcher serves needs per step (0.7-0.8 ms).
+// asynchronous launcher's (csrc/launcher.hip) -- must not get the default-priority lanes: its caller leaves a blocked
+// hipStreamWaitValue64 on ITS stream until the job is done, and a lane that happened to share that stream's hardware queue
+// (few queues, many application streams) would sit behind the blocked wait while the job waits for the lane: a deadlock.
+// The runtime pools hardware queues PER PRIORITY, so a lane is safe when its priority differs from the waiting stream's.
+// Lanes of a priority other than the default one were MEASURED at 2.3-2.5 ms per step instead of 0.46, both at the
+// launcher's own (highest) priority and at the lowest (round 5, profiles/r05_ref_loop_probe.txt: this
+// runtime does not run streams of a non-default pool side by side with the job's).  So a launcher job's gradient work runs
+// INLINE on `main`: the step's kernels serialise (0.66 ms of GPU time, profiles/r05_ref_loop_trace.txt) and the reference loop
+// lands at 0.75 ms, GPU-bound.  The debug switch launcher_lanes = 1 selects the lowest-priority pair (the measurement).
 // (caller holds the device's LaneLock)
 static int lanes_for(SideStream* s, hipStream_t main, hipStream_t* conv, hipStream_t* dense) {
   *conv = s->stream;
@@ -236,6 +239,13 @@ static int lanes_for(SideStream* s, hipStream_t main, hipStream_t* conv, hipStre
   if (hipStreamGetPriority(main, &pr) != hipSuccess || pr != hi) return MVH_OK;
   *conv = main;
   *dense = main;
+  if (!dbg().launcher_lanes || lo <= 0) return MVH_OK;      // no priority level below the default one: inline
+  if (!s->lstream) {
+    MVH_HIP(hipStreamCreateWithPriority(&s->lstream, hipStreamNonBlocking, lo));
+    MVH_HIP(hipStreamCreateWithPriority(&s->ldense, hipStreamNonBlocking, lo));
+  }
+  *conv = s->lstream;
+  *dense = s->ldense;
   return MVH_OK;
 }
 

@@ -28,6 +28,9 @@ def main():
         torch.autograd.set_multithreading_enabled(False)
     dev = torch.device("cuda:0")
     B = a.batch
+    if "PROBE_LAUNCHER_LANES" in os.environ:               # 0: launcher jobs run their gradient work inline; 1: lowest-priority lanes
+        from meshvae_hip import check, lib
+        check(lib().mvh_debug_set(b"launcher_lanes", int(os.environ["PROBE_LAUNCHER_LANES"])))
     x = torch.randn(B, 4998, 3, generator=torch.Generator().manual_seed(0)).to(dev)
     x_gt = x.double()
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
