@@ -51,8 +51,26 @@ struct PatchDims {
   int x_bs;             // rows per mesh of the layer input x (N, or the mesh stride of a strided view in rows)
 };
 
+// float4 sums / fused multiply-adds as TWO packed instructions (v_pk_add_f32 / v_pk_fma_f32: two fp32 lanes per issue slot,
+// the same IEEE operations per component) -- the gather loops are bound by vector-instruction issue, and the build runs
+// without the SLP vectoriser that would pair the scalar forms
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) {
+#ifdef MVH_NO_PK
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+#endif
+  const f32x2_v lo = (f32x2_v){a.x, a.y} + (f32x2_v){b.x, b.y}, hi = (f32x2_v){a.z, a.w} + (f32x2_v){b.z, b.w};
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+// c g - s per component
+__device__ __forceinline__ float4 f4fms(float c, const float4& g, const float4& s) {
+#ifdef MVH_NO_PK
+  return make_float4(fmaf(c, g.x, -s.x), fmaf(c, g.y, -s.y), fmaf(c, g.z, -s.z), fmaf(c, g.w, -s.w));
+#endif
+  const f32x2_v cc = {c, c};
+  const f32x2_v lo = __builtin_elementwise_fma(cc, (f32x2_v){g.x, g.y}, -(f32x2_v){s.x, s.y});
+  const f32x2_v hi = __builtin_elementwise_fma(cc, (f32x2_v){g.z, g.w}, -(f32x2_v){s.z, s.w});
+  return make_float4(lo[0], lo[1], hi[0], hi[1]);
 }
 
 // LDS byte offset of quad q (qoff = 16 q) of the row whose id (5 x local id, one 16-bit half of w) the list holds:
@@ -238,9 +256,8 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
       const float ca = coef_l[s * NW * 16] * sc, cb = coef_l[(s + 1) * NW * 16] * sc;
       float4 ga, gb;
       gather8x2(smem, 16u * q, ia, ib, padw, ga, gb);
-      st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
-      st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
-                              fmaf(cb, gb.w, -st[s + 1].w));
+      st[s] = f4fms(ca, ga, st[s]);
+      st[s + 1] = f4fms(cb, gb, st[s + 1]);
       if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);
       if (s + 1 < ASLOTS) mfma4(acc[s + 1 < ASLOTS ? s + 1 : 0], wa, st[s + 1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -252,8 +269,7 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
         const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
         const float cc = coef_l[s * NW * 16] * sc;
         const float4 g = gather8(smem, 16u * q, id, padw);
-        st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
-                            fmaf(cc, g.w, -st[s].w));
+        st[s] = f4fms(cc, g, st[s]);
         if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, st[s]);   // (tiles past the last output tile: unused columns)
       }
       __builtin_amdgcn_sched_barrier(0);   // one slot's gathers in flight at a time (registers)
@@ -486,9 +502,8 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         const float ca = coef_l[s * NWR * 16] * sc, cb = coef_l[(s + 1) * NWR * 16] * sc;
         float4 ga, gb;
         gather8x2(smem, 16u * q, ia, ib, padw, ga, gb);
-        st[s] = make_float4(fmaf(ca, ga.x, -st[s].x), fmaf(ca, ga.y, -st[s].y), fmaf(ca, ga.z, -st[s].z), fmaf(ca, ga.w, -st[s].w));
-        st[s + 1] = make_float4(fmaf(cb, gb.x, -st[s + 1].x), fmaf(cb, gb.y, -st[s + 1].y), fmaf(cb, gb.z, -st[s + 1].z),
-                                fmaf(cb, gb.w, -st[s + 1].w));
+        st[s] = f4fms(ca, ga, st[s]);
+        st[s + 1] = f4fms(cb, gb, st[s + 1]);
         pin(st[s]);
         pin(st[s + 1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -500,8 +515,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
           const uint4 id = *reinterpret_cast<const uint4*>(rowp(s) + 64);
           const float cc = coef_l[s * NWR * 16] * sc;
           const float4 g = gather8(smem, 16u * q, id, padw);
-          st[s] = make_float4(fmaf(cc, g.x, -st[s].x), fmaf(cc, g.y, -st[s].y), fmaf(cc, g.z, -st[s].z),
-                              fmaf(cc, g.w, -st[s].w));
+          st[s] = f4fms(cc, g, st[s]);
           pin(st[s]);
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -162,13 +162,31 @@ struct SideStream {
   int next_ev = 0;
   hipEvent_t dense_done = nullptr;  // recorded after the dense-layer weight gradients of the last backward
   bool dense_recorded = false;
-  // mvh_vae_backward_prefetch: the first layer's Chebyshev stack is already being built on the side lane
-  hipEvent_t tstack_done = nullptr;
-  const void* tstack_x = nullptr;
-  const void* tstack_ws = nullptr;
-  hipStream_t tstack_stream = nullptr;
-  bool tstack_pending = false;   // launched: mvh_vae_backward only waits for tstack_done
-  bool tstack_armed = false;     // requested: the next mvh_vae_forward on (tstack_x, tstack_ws) launches it
+  // mvh_vae_backward_prefetch: the first layer's Chebyshev stack is already being built on the side lane.  The state is
+  // kept PER WORKSPACE (= per chain: TrainStep n_micro > 1 drives several from several host threads), so that one chain's
+  // prefetch call or backward never disarms another's; kPrefetchSlots chains at a time, the least recently armed one is
+  // recycled (a chain that loses its slot only loses the overlap: its backward builds the stack itself).
+  static constexpr int kPrefetchSlots = 4;
+  struct Prefetch {
+    hipEvent_t done = nullptr;
+    const void* x = nullptr;
+    const void* ws = nullptr;
+    hipStream_t stream = nullptr;
+    bool pending = false;   // launched: mvh_vae_backward only waits for `done`
+    bool armed = false;     // requested: the next mvh_vae_forward on (x, ws) launches it
+    unsigned long long stamp = 0;
+  } pf[kPrefetchSlots];
+  unsigned long long pf_clock = 0;
+  Prefetch* prefetch_of(const void* ws, bool take) {
+    Prefetch* lru = &pf[0];
+    for (Prefetch& q : pf) {
+      if (q.ws == ws) return &q;
+      if (q.stamp < lru->stamp) lru = &q;
+    }
+    if (!take) return nullptr;
+    lru->ws = ws; lru->x = nullptr; lru->stream = nullptr; lru->pending = lru->armed = false;
+    return lru;
+  }
 };
 
 // ONE set of gradient lanes per DEVICE, shared by every host thread, behind a per-device lock that an entry point holds for
@@ -214,7 +232,8 @@ static SideStream* side_for_device() {
     // dense_done is the one event whose data can leave the device (mvh_vae_wait_dense_grads hands the dense gradients to an
     // RCCL stream that peer GPUs read): it keeps the default system-scope fence
     if (hipEventCreateWithFlags(&s.dense_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.tstack_done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
+    for (SideStream::Prefetch& q : s.pf)
+      if (hipEventCreateWithFlags(&q.done, hipEventDisableTiming | kEvFlags) != hipSuccess) return nullptr;
     s.n_ev = 64;
   }
   return &s;
@@ -486,7 +505,8 @@ extern "C" int mvh_vae_backward_prefetch(mvh_stream_t stream, const mvh_vae_desc
   LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward_prefetch: could not create the side stream");
-  side->tstack_pending = side->tstack_armed = false;
+  SideStream::Prefetch* pf = side->prefetch_of(ws, true);
+  pf->pending = pf->armed = false;
   const bool use_tstack = tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0]) &&
                           d->down[0].n_rows == p.Nn[1] && !dbg().no_tstack && !dbg().no_prefetch;
   hipStream_t main = (hipStream_t)stream;
@@ -494,23 +514,24 @@ extern "C" int mvh_vae_backward_prefetch(mvh_stream_t stream, const mvh_vae_desc
   TRY(lanes_for(side, main, &lane_conv, &lane_dense));
   hipStream_t sstream = side_stream ? (hipStream_t)side_stream : lane_conv;
   if (!use_tstack || dbg().no_side || sstream == main) return MVH_OK;   // nothing to run ahead: the backward does it all
-  side->tstack_x = x; side->tstack_ws = ws; side->tstack_stream = sstream; side->tstack_armed = true;
+  pf->x = x; pf->stream = sstream; pf->armed = true; pf->stamp = ++side->pf_clock;
   return MVH_OK;
 }
 
 // (called by the forward after its first convolution)
 static int run_armed_prefetch(SideStream* side, hipStream_t main, const mvh_vae_desc_t* d, const StepPlan& p,
                               const float* x, void* ws, int B) {
-  if (!side || !side->tstack_armed || side->tstack_x != x || side->tstack_ws != ws) return MVH_OK;
-  side->tstack_armed = false;
-  hipStream_t sstream = side->tstack_stream;
+  SideStream::Prefetch* pf = side ? side->prefetch_of(ws, false) : nullptr;
+  if (!pf || !pf->armed || pf->x != x) return MVH_OK;
+  pf->armed = false;
+  hipStream_t sstream = pf->stream;
   int& ev = side->next_ev;
   MVH_HIP(hipEventRecord(side->ev[ev], main));          // (the previous step's reader of the stack is behind this point)
   MVH_HIP(hipStreamWaitEvent(sstream, side->ev[ev], 0));
   ev = (ev + 1) % side->n_ev;
   TRY(launch_tstack(sstream, &d->lap[0], &d->down[0], x, F(p.tstack), B, p.Nn[0], p.f[0], d->K[0]));
-  MVH_HIP(hipEventRecord(side->tstack_done, sstream));
-  side->tstack_pending = true;
+  MVH_HIP(hipEventRecord(pf->done, sstream));
+  pf->pending = true;
   return MVH_OK;
 }
 
@@ -530,6 +551,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_backward: could not create the side stream");
+  SideStream::Prefetch* pf = side->prefetch_of(ws, false);      // this chain's prefetch state, if it has any
   hipStream_t lane_conv = nullptr, lane_dense = nullptr;
   TRY(lanes_for(side, main, &lane_conv, &lane_dense));
   hipStream_t sstream = side_stream ? (hipStream_t)side_stream : lane_conv;
@@ -818,8 +840,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       MVH_REQUIRE(dfr, "vae_backward: the patch kernel did not defer its weight-gradient reduction");
       ++red.n;
       if (i == n - 1 && use_tstack) {
-        if (side->tstack_pending && side->tstack_x == x && side->tstack_ws == ws && side->tstack_stream == sstream) {
-          ev_tstack = side->tstack_done;      // built ahead of the forward (mvh_vae_backward_prefetch)
+        if (pf && pf->pending && pf->x == x && pf->stream == sstream) {
+          ev_tstack = pf->done;      // built ahead of the forward (mvh_vae_backward_prefetch)
         } else {
           TRY(flush_dw(false));
           MVH_HIP(hipEventRecord(side->ev[ev], main));
@@ -832,7 +854,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
             ev = (ev + 1) % side->n_ev;
           }
         }
-        side->tstack_pending = false;
+        if (pf) pf->pending = false;
       }
       continue;
     }
@@ -841,8 +863,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
                      p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));
     if (i == n - 1 && use_tstack) {
-      if (side->tstack_pending && side->tstack_x == x && side->tstack_ws == ws && side->tstack_stream == sstream) {
-        ev_tstack = side->tstack_done;      // built ahead of the forward (mvh_vae_backward_prefetch)
+      if (pf && pf->pending && pf->x == x && pf->stream == sstream) {
+        ev_tstack = pf->done;      // built ahead of the forward (mvh_vae_backward_prefetch)
       } else {
         // T_k x of encoder layer 0 at its pooled rows: 64 workgroups on the side lane behind the (chip-filling)
         // dW above, i.e. while the main chain runs its small-level kernels; consumed at the very end
@@ -853,7 +875,7 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
           ev = (ev + 1) % side->n_ev;
         }
       }
-      side->tstack_pending = false;
+      if (pf) pf->pending = false;
     }
     if (!dx_first) TRY(dx_this());
   }
@@ -1004,7 +1026,7 @@ extern "C" int mvh_vae_wait_dense_grads(mvh_stream_t stream) {
   LaneLock lanes;
   SideStream* side = side_for_device();
   MVH_REQUIRE(side != nullptr, "vae_wait_dense_grads: no device");
-  MVH_REQUIRE(side->dense_recorded, "vae_wait_dense_grads: no mvh_vae_backward was issued from this thread on this device");
+  MVH_REQUIRE(side->dense_recorded, "vae_wait_dense_grads: no mvh_vae_backward was issued on this device");
   MVH_HIP(hipStreamWaitEvent((hipStream_t)stream, side->dense_done, 0));
   return MVH_OK;
 }

@@ -415,11 +415,34 @@ class cheb_VAE(torch.nn.Module):
         return loss, correct, x, [kld, rec_loss, z_], y_hat
 
     def _all_params_require_grad(self):
-        """(over a cached list: walking the module tree with .parameters() costs ~40 us per call)"""
+        """(over a cached list: walking the module tree with .parameters() costs ~40 us per call.  The list holds, per
+        parameter, the owning module's _parameters dict and its key: a Parameter OBJECT that was replaced since --
+        `net.cls.weight = nn.Parameter(...)`, parametrizations, conversions under
+        torch.__future__.set_overwrite_module_params_on_conversion -- is seen by identity, and every cache that names the
+        old objects (this list, the fused entries with their gradient views) is dropped and rebuilt.)"""
         ps = self.__dict__.get("_param_list")
         if ps is None:
-            ps = self.__dict__["_param_list"] = [p for _, p in self.named_parameters()]
-        for p in ps:
+            ps = self.__dict__["_param_list"] = self._param_triples()
+        for d, n, p in ps:
+            if d.get(n) is not p:
+                self._drop_param_caches()
+                return self._all_params_require_grad()
             if not p.requires_grad:
                 return False
         return True
+
+    def _param_triples(self):
+        out, seen = [], set()
+        for m in self.modules():
+            for n, p in m._parameters.items():
+                if p is not None and id(p) not in seen:      # (named_parameters' order and de-duplication)
+                    seen.add(id(p))
+                    out.append((m._parameters, n, p))
+        return out
+
+    def _drop_param_caches(self):
+        import meshvae_hip
+        self.__dict__.pop("_param_list", None)
+        for ent in self.__dict__.pop("_fused_cache", {}).values():
+            if ent["launcher"] is not None:          # (its workspace may still be named by a queued job)
+                meshvae_hip.check(meshvae_hip.lib().mvh_launcher_sync(ent["launcher"]))

@@ -798,6 +798,45 @@ def _ref_model(which, dev, dropout=0.0):
     return cheb_VAE(3, dict(cfg, dropout=dropout), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
 
 
+def test_module_path_sees_a_replaced_parameter_object():
+    """the module path caches its parameter list and, per batch size, a native step with the gradient
+    views.  A Parameter OBJECT replaced after the first call (net.cls.weight = nn.Parameter(...)) must not leave the fused
+    step training the old tensor: the identity check in cheb_VAE._all_params_require_grad drops the caches, the next call
+    reads the new weights and its gradient lands on the new object -- the same numbers as a fresh model holding them."""
+    from meshvae_hip.engine import _Batch
+    dev = torch.device("cuda:0")
+    B, N = 4, 162
+    x = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    for mode in ("autograd", "assign"):
+        net = _ref_model("tiny", dev).train()
+        net.dropout.p = 0.0
+        net.grad_mode = mode
+        eps = torch.randn(B, net.z, generator=torch.Generator().manual_seed(4)).to(dev)
+        net._eps_provider = lambda B_, Z_, d_: eps
+        net(_Batch(x), x, y, m_type="train")[0].backward()
+        name, old = next((n, p) for n, p in net.named_parameters() if n.endswith("weight"))
+        mod = net.get_submodule(name.rsplit(".", 1)[0])
+        fresh = torch.nn.Parameter(old.detach() * 0.5 + 0.01)
+        setattr(mod, name.rsplit(".", 1)[1], fresh)
+        for p in net.parameters():
+            p.grad = None
+        loss = net(_Batch(x), x, y, m_type="train")[0]
+        loss.backward()
+        assert fresh.grad is not None and float(fresh.grad.abs().sum()) > 0, (mode, name)
+        ref = _ref_model("tiny", dev).train()
+        ref.dropout.p = 0.0
+        ref._eps_provider = lambda B_, Z_, d_: eps
+        ref.load_state_dict(net.state_dict())
+        l2 = ref(_Batch(x), x, y, m_type="train")[0]
+        l2.backward()
+        assert float(loss.detach()) == float(l2.detach()), mode
+        got = dict(net.named_parameters())
+        for n, p in ref.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(got[n].grad, p.grad), (mode, n)
+
+
 @pytest.mark.parametrize("which,B", [("tiny", 6), ("5k", 4)])
 def test_reference_loop_ends_where_trainstep_ends(which, B):
     """The reference's own loop over the drop-in modules (main.py:74-81,251: zero_grad -> net(data, x_gt, y) ->
