@@ -1056,6 +1056,17 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   if (!tx_saved && !bf && !pool && patch_eligible(lap, N, Cin, Cout, K) &&
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)W) & 15) == 0)
     return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs);
+  // the first layer (<= 4 -> 16) in front of its one-hot pooling, nobody reading the other rows: recurrence on the input
+  // side in the patch image, pooled rows + their sign bytes + the weight gradient's T_k stack out of one launch (`out`
+  // itself is never written: io.out, its storage type, does not matter)
+  if (!tx_saved && !io.x && !io.x_map && pool && pooled && io.out_dead && !dbg().keep_enc_out &&
+      act == MVH_ACT_RELU && patch_enc0_eligible(lap, pool, N, Cin, Cout, K) &&
+      (((uintptr_t)pooled | (uintptr_t)bias | (uintptr_t)io.stack_out) & 15) == 0) {
+    if (int rc = launch_patch_enc0(st, lap, pool, x, W, bias, pooled, io.pooled, bits_out, io.stack_out, B, N, Cin, K, act))
+      return rc;
+    if (io.stack_out && io.stack_done) *io.stack_done = true;
+    return MVH_OK;
+  }
   if (!tx_saved) {  // fused path: one launch, no T_k stack
     bool handled = false;
     float* wpack = (ws && ws_bytes >= kLdsWpackBytes) ? (float*)ws : nullptr;

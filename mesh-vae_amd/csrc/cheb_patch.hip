@@ -33,6 +33,7 @@
 //   the patch (every vertex once).  Per (patch, wave, order) partial tiles in the layout of launch_dw_reduce_all.
 //   The pooling behind dX (U^T, nn/pool.py:17-20 backward) is formed from LDS for the coarse rows the plan assigns.
 #include "common.hpp"
+#include "bf16.hpp"
 
 namespace mvh {
 
@@ -49,6 +50,8 @@ struct PatchDims {
   int has_dw, has_dx;
   int pool_lds;         // the pooling entries of every patch fit the LDS behind its core rows
   int x_bs;             // rows per mesh of the layer input x (N, or the mesh stride of a strided view in rows)
+  int cin;              // k_patch_enc0: input channels (<= 4)
+  int out_bf16;         // k_patch_enc0: the pooled output rows are stored as bf16 (bf16.hpp)
 };
 
 // float4 sums / fused multiply-adds as TWO packed instructions (v_pk_add_f32 / v_pk_fma_f32: two fp32 lanes per issue slot,
@@ -724,6 +727,155 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
   MVH_STAMPX(28);
 }
 
+// ------------------------------------------------------------------------------------- first layer: <= 4 -> 16 channels
+// cheb.0 of the encoder (cheb_VAE.py:264) followed by its one-hot downsampling (nn/pool.py D): x has <= 4 channels, and
+// only the rows D selects (1250 of 4998) are read by anybody -- the next layer, and the layer's own weight gradient, which
+// needs T_k(L) x at exactly those rows (cheb_tstack.hip).  So the recurrence runs on the INPUT side, one float4 per vertex
+// (a quarter of the 16-channel recurrence the output-side Clenshaw form of cheb_lds.hip runs for this layer), in the same
+// patch image as the 16 -> 16 kernels: a lane owns a ROW here (no matrix operand layout to respect).  After every order
+// the pooled rows the plan assigns to the patch are read back from LDS in the pooling operator's row order:
+//   stack[mesh][k][row] = T_k x (D^1/2 applied)  -- the plane k_stack_dw reads in the backward (no k_cheb_tstack launch),
+//   acc[row][16] += T_k x W_k                     -- one lane per (row, 4 output channels), weights from LDS,
+// and the epilogue stores relu(acc + bias) and its sign byte at the pooled rows only.
+// SLOTS >= rows of the largest patch / THREADS; TS >= 4 x pooled rows of a patch / THREADS.
+template <int THREADS, int SLOTS, int TS>
+__global__ void __launch_bounds__(THREADS)
+k_patch_enc0(const float* __restrict__ p_x, const float* __restrict__ p_W, const float* __restrict__ p_bias,
+             float* __restrict__ p_pooled, uint8_t* __restrict__ p_bits, float* __restrict__ p_stack,
+             const int32_t* __restrict__ p_poff, const int32_t* __restrict__ p_cnt, const uint32_t* __restrict__ p_pinfo,
+             const uint32_t* __restrict__ p_ell, const int32_t* __restrict__ p_prow_off,
+             const int32_t* __restrict__ p_prow_gid, const int32_t* __restrict__ p_prow_ptr,
+             const int32_t* __restrict__ p_pcol, PatchDims a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mesh = (jj / a.P) * 8 + xcd, pt = jj % a.P;
+  if (mesh >= a.B) return;
+  const int tid = threadIdx.x;
+  const int o = p_poff[pt], rows16 = p_poff[pt + 1] - o;
+  const int* __restrict__ c = p_cnt + pt * (a.R + 2);
+  const int K = a.K;
+  const unsigned padw = (unsigned)(rows16 * 5) * 0x10001u;
+  float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);   // [rows16]
+  float* wl = coefv + rows16;                                                     // [K][4][16], rows >= cin zero
+  MVH_STAMPX(0);
+  for (int i = tid; i < rows16; i += THREADS) {
+    *reinterpret_cast<uint4*>(smem + (size_t)i * kRowB + 64) = reinterpret_cast<const uint4*>(p_ell)[o + i];
+    const float deg = (float)((p_pinfo[o + i] >> 16) & 255u);
+    coefv[i] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
+  }
+  if (tid == 0) *reinterpret_cast<float4*>(smem + (size_t)rows16 * kRowB) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < K * 64; i += THREADS) {
+    const int k = i >> 6, ci = (i >> 4) & 3, co = i & 15;
+    wl[i] = ci < a.cin ? p_W[(k * a.cin + ci) * 16 + co] : 0.f;
+  }
+  const int n0 = c[1 + min(a.R, K - 1)];           // rows whose u_0 somebody needs
+  const float* xb = p_x + (long long)mesh * a.x_bs * a.cin;
+  float4 st[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * THREADS + tid;
+    st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < n0) {
+      const uint32_t info = p_pinfo[o + v];
+      const float deg = (float)((info >> 16) & 255u);
+      if ((info >> 24 & 15u) != 15u) {
+        const float sc = deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f;
+        const float* xr = xb + (long long)(info & 0xffffu) * a.cin;
+        r.x = xr[0] * sc;
+        if (a.cin > 1) r.y = xr[1] * sc;
+        if (a.cin > 2) r.z = xr[2] * sc;
+        if (a.cin > 3) r.w = xr[3] * sc;
+      }
+    }
+    if (v < rows16) *reinterpret_cast<float4*>(smem + (size_t)v * kRowB) = r;
+  }
+  // the pooled rows of this patch: lane task (row i, output quad q); a dead task reads the zero row
+  const int r0 = p_prow_off[pt], nrow = p_prow_off[pt + 1] - r0;
+  const int* __restrict__ rp = p_prow_ptr + r0 + pt;
+  const int n_sel = a.n_pool_rows;
+  int lc[TS], grow[TS];
+  float is[TS];
+  float4 acc[TS];
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    const int t = j * THREADS + tid, i = t >> 2;
+    const bool live = i < nrow;
+    lc[j] = live ? p_pcol[rp[i]] : rows16;
+    grow[j] = live ? p_prow_gid[r0 + i] : -1;
+    const float deg = live ? (float)((p_pinfo[o + lc[j]] >> 16) & 255u) : 0.f;
+    is[j] = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int q = tid & 3;
+  float4* const sbase = reinterpret_cast<float4*>(p_stack) + (long long)mesh * K * (n_sel + 1);
+  auto contract = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+      if (j * THREADS + (tid & ~63) >= 4 * nrow) continue;        // (wave-uniform: no task of this wave is live)
+      const float4 uv = *reinterpret_cast<const float4*>(smem + (size_t)lc[j] * kRowB);
+      const float4 T = make_float4(uv.x * is[j], uv.y * is[j], uv.z * is[j], uv.w * is[j]);
+      if (p_stack && q == 0 && grow[j] >= 0) sbase[(long long)k * (n_sel + 1) + grow[j]] = T;
+      const float4 w0 = *reinterpret_cast<const float4*>(wl + (k * 4 + 0) * 16 + 4 * q);
+      const float4 w1 = *reinterpret_cast<const float4*>(wl + (k * 4 + 1) * 16 + 4 * q);
+      const float4 w2 = *reinterpret_cast<const float4*>(wl + (k * 4 + 2) * 16 + 4 * q);
+      const float4 w3 = *reinterpret_cast<const float4*>(wl + (k * 4 + 3) * 16 + 4 * q);
+      acc[j].x = fmaf(T.w, w3.x, fmaf(T.z, w2.x, fmaf(T.y, w1.x, fmaf(T.x, w0.x, acc[j].x))));
+      acc[j].y = fmaf(T.w, w3.y, fmaf(T.z, w2.y, fmaf(T.y, w1.y, fmaf(T.x, w0.y, acc[j].y))));
+      acc[j].z = fmaf(T.w, w3.z, fmaf(T.z, w2.z, fmaf(T.y, w1.z, fmaf(T.x, w0.z, acc[j].z))));
+      acc[j].w = fmaf(T.w, w3.w, fmaf(T.z, w2.w, fmaf(T.y, w1.w, fmaf(T.x, w0.w, acc[j].w))));
+    }
+  };
+  MVH_STAMPX(1);
+  __syncthreads();
+  MVH_STAMPX(2);
+  contract(0);
+  for (int k = 1; k < K; ++k) {
+    const int lim = c[1 + min(a.R, K - 1 - k)];      // rows whose u_k somebody needs
+    const float sc = (k == 1) ? 0.5f : 1.0f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int v = s * THREADS + tid;
+      if (v < lim) {
+        const uint4 id = *reinterpret_cast<const uint4*>(smem + (size_t)v * kRowB + 64);
+        const float cc = coefv[v] * sc;
+        const float4 g = gather8(smem, 0u, id, padw);
+        st[s] = f4fms(cc, g, st[s]);
+      }
+    }
+    MVH_STAMPX(3 + 3 * (k - 1));
+    __syncthreads();            // every gather of u_{k-1} is done
+    MVH_STAMPX(4 + 3 * (k - 1));
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int v = s * THREADS + tid;
+      if (v < lim) {
+        float4* own = reinterpret_cast<float4*>(smem + (size_t)v * kRowB);
+        const float4 old = *own;
+        *own = st[s];
+        st[s] = old;
+      }
+    }
+    __syncthreads();            // u_k is in LDS (its readers: contract(k) now, the gathers of order k + 1)
+    MVH_STAMPX(5 + 3 * (k - 1));
+    contract(k);
+  }
+  MVH_STAMPX(26);
+  const float4 b4 = p_bias ? *reinterpret_cast<const float4*>(p_bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    if (grow[j] < 0) continue;
+    float r0v = acc[j].x + b4.x, r1v = acc[j].y + b4.y, r2v = acc[j].z + b4.z, r3v = acc[j].w + b4.w;
+    if (a.act == MVH_ACT_RELU) { r0v = fmaxf(r0v, 0.f); r1v = fmaxf(r1v, 0.f); r2v = fmaxf(r2v, 0.f); r3v = fmaxf(r3v, 0.f); }
+    store4_any(p_pooled, ((long long)mesh * n_sel + grow[j]) * 16 + 4 * q, a.out_bf16 != 0, r0v, r1v, r2v, r3v);
+    if (p_bits) {
+      const long long vrow = (long long)mesh * a.N + (p_pinfo[o + lc[j]] & 0xffffu);
+      p_bits[vrow * 4 + q] = (uint8_t)((r0v > 0.f ? 1 : 0) | (r1v > 0.f ? 2 : 0) | (r2v > 0.f ? 4 : 0) | (r3v > 0.f ? 8 : 0));
+    }
+  }
+  MVH_STAMPX(27);
+}
+
 #ifdef MVH_STAMP
 MVH_STAMP_READER(mvh_debug_read_stamps_patch)
 #endif
@@ -823,6 +975,49 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
   hipLaunchKernelGGL(kern, dim3(grid), dim3((C::NWR + C::NWD) * 64), lds, st, dout, mbits, g3, w3, x, x_map, W, dx, part,
                      pl->poff, pl->cnt, pl->pinfo, pl->ell, pl->prow_off, pl->prow_gid, pl->prow_ptr, pl->pcol, pl->pval, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// ---- first layer (<= 4 -> 16 channels + one-hot pooling): the plan hangs off the POOLING operator (down->patch), built
+// from the level's Laplacian with that operator's rows as its pooling rows (topology.patch_plan(.., down_op=))
+struct Enc0Cfg { static constexpr int THREADS = 1024, SLOTS = 2, TS = 2; };
+
+static size_t enc0_lds_bytes(const mvh_patch_plan_t* pl, int K) {
+  return (size_t)(pl->max_rows + 1) * kRowB + (size_t)pl->max_rows * 4 + (size_t)K * 64 * 4;
+}
+
+bool patch_enc0_eligible(const mvh_csr_t* lap, const mvh_csr_t* down, int N, int Cin, int Cout, int K) {
+  if (dbg().no_patch || dbg().no_enc0_patch || dbg().force_generic) return false;
+  const mvh_patch_plan_t* pl = down ? down->patch : nullptr;
+  if (!pl || !lap || Cin < 1 || Cin > 4 || Cout != 16 || K < 1 || K > 12) return false;
+  const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
+  if ((lap->flags & need) != need || !(down->flags & MVH_CSR_SELECTION)) return false;
+  if (pl->n_vertices != N || down->n_cols != N || pl->n_patches < 1 || K - 1 > pl->n_rings) return false;
+  if (pl->n_pool_rows != down->n_rows || pl->pool_rowptr != down->rowptr) return false;
+  if (pl->max_rows % 16 != 0 || pl->max_rows < 16 || pl->max_rows > Enc0Cfg::THREADS * Enc0Cfg::SLOTS) return false;
+  if (4 * pl->max_pool_nnz > Enc0Cfg::THREADS * Enc0Cfg::TS) return false;      // (one entry per pooled row)
+  return enc0_lds_bytes(pl, K) <= 160 * 1024;
+}
+
+int launch_patch_enc0(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* down, const float* x, const float* W,
+                      const float* bias, float* pooled, bool pooled_bf16, uint8_t* bits, float* stack, int B, int N,
+                      int Cin, int K, int act) {
+  const mvh_patch_plan_t* pl = down->patch;
+  MVH_REQUIRE(x && W && pooled, "patch_enc0: null tensor");
+  MVH_REQUIRE((((uintptr_t)pooled | (uintptr_t)bias | (uintptr_t)stack) & 15) == 0 && ((uintptr_t)x & 3) == 0,
+              "patch_enc0: tensors must be 16-byte aligned");
+  PatchDims d{};
+  d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = act;
+  d.x_bs = N; d.cin = Cin; d.out_bf16 = pooled_bf16 ? 1 : 0; d.n_pool_rows = pl->n_pool_rows;
+  using C = Enc0Cfg;
+  auto kern = k_patch_enc0<C::THREADS, C::SLOTS, C::TS>;
+  const size_t lds = enc0_lds_bytes(pl, K);
+  static LdsAttr attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
+  const int grid = ((d.B + 7) / 8) * 8 * d.P;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, W, bias, pooled, bits, stack, pl->poff, pl->cnt,
+                     pl->pinfo, pl->ell, pl->prow_off, pl->prow_gid, pl->prow_ptr, pl->pcol, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

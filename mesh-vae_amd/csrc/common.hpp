@@ -132,6 +132,7 @@ struct DebugCfg {
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
+  int no_enc0_patch = 0;   // 1: the first layer's forward stays on the slab kernel and the backward builds its stack (k_cheb_tstack)
   int patch_flush_first = 1;   // the step forks the weight-gradient items queued so far (the final layer's) BEFORE a patch backward
                                // launch, so that they run beside it (MEASURED: 458 against 485 us per step; 0: behind it)
   int keep_enc_out = 0;    // 1: the encoder convs store their whole output and every sign byte (ConvIO::out_dead off)
@@ -268,6 +269,11 @@ struct ConvIO {
   // weight gradient of the 5k level (k_cheb_dw_lds<.., 10, 512, ..>: one 160 KB workgroup per CU): the batch in dw_split
   // launches one behind the other, so that the kernel holds 1 / dw_split of the CUs at a time (the step engine's level-0 lane)
   int dw_split = 1;
+  // forward of the first layer (<= 4 -> 16 channels, ReLU, one-hot pooling, out_dead) on the vertex-patch kernel
+  // (cheb_patch.hip, k_patch_enc0): it also leaves T_k(L) x at the pooled rows, the stack [B][K][n_sel + 1][4] of
+  // cheb_tstack.hip, in stack_out, and says so in *stack_done (left untouched on every other path)
+  float* stack_out = nullptr;
+  bool* stack_done = nullptr;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?
@@ -297,6 +303,10 @@ int cheb_conv_bwd_impl(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* la
 constexpr size_t kLdsWpackBytes = 64 * 1024;
 // vertex-patch kernels of a level's 16 -> 16 layers (cheb_patch.hip; the plan hangs off the Laplacian: mvh_csr_t::patch)
 bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K);
+bool patch_enc0_eligible(const mvh_csr_t* lap, const mvh_csr_t* down, int N, int Cin, int Cout, int K);
+int launch_patch_enc0(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* down, const float* x, const float* W,
+                      const float* bias, float* pooled, bool pooled_bf16, uint8_t* bits, float* stack, int B, int N,
+                      int Cin, int K, int act);
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K);
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
                      uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map = nullptr /* ConvIO::x_map */,

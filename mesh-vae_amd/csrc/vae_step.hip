@@ -171,7 +171,8 @@ struct SideStream {
     hipEvent_t done = nullptr;
     const void* x = nullptr;
     const void* ws = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the lane it was launched on; null: written by the forward's first layer itself
+    hipStream_t fwd = nullptr;      // ... then: the forward's stream (a backward on the same stream needs no wait)
     bool pending = false;   // launched: mvh_vae_backward only waits for `done`
     bool armed = false;     // requested: the next mvh_vae_forward on (x, ws) launches it
     unsigned long long stamp = 0;
@@ -396,7 +397,15 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     ConvIO io;
     io.x = bf && i > 0; io.out = bf; io.pooled = bf && i + 1 < n;   // (the last pooled level feeds the fp32 dense head)
     // the un-pooled rows have no reader (the backward takes the ReLU signs from the sign bytes, and only at the pooled rows)
-    io.out_dead = p.encBits[i] != kNoBits && !dbg().keep_enc_out;
+    // (inference plans keep no sign bytes: only the first layer's patch kernel takes the hint without them)
+    io.out_dead = (p.encBits[i] != kNoBits || i == 0) && !dbg().keep_enc_out;
+    // the first layer on the patch kernel leaves its T_k stack for the backward's weight gradient (no k_cheb_tstack launch)
+    bool stack_done = false;
+    if (i == 0 && phases == kPhAll && d->down[0].n_rows == p.Nn[1] && !dbg().no_tstack &&
+        tstack_eligible(&d->lap[0], &d->down[0], p.Nn[0], p.f[0], p.f[1], d->K[0])) {
+      io.stack_out = F(p.tstack);
+      io.stack_done = &stack_done;
+    }
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[i], cur, P[ix.encW(i)], P[ix.encB(i)], F(p.encA[i]),
                            bf ? nullptr : TX(p.txEnc[i]), B,
                            p.Nn[i], p.f[i], p.f[i + 1], d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_enc_f[i]),
@@ -404,6 +413,15 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     cur = F(p.encP[i]);
     // the armed first-layer stack (mvh_vae_backward_prefetch) starts behind encoder stage `prefetch_at` (debug switch,
     // default 0; MEASURED 0 .. 3 on one box: 553 .. 555 us per step, no difference)
+    if (stack_done) {        // (tells mvh_vae_backward on this workspace, and disarms a requested prefetch)
+      LaneLock lanes;
+      SideStream* side = side_for_device();
+      MVH_REQUIRE(side != nullptr, "vae_forward: could not create the side stream");
+      SideStream::Prefetch* pf = side->prefetch_of(ws, true);
+      pf->x = x; pf->stream = nullptr; pf->fwd = (hipStream_t)stream; pf->armed = false; pf->pending = true;
+      pf->stamp = ++side->pf_clock;
+      MVH_HIP(hipEventRecord(pf->done, (hipStream_t)stream));
+    }
     if (i == min(max(dbg().prefetch_at, 0), n - 1) && phases == kPhAll) {
       LaneLock lanes;
       TRY(run_armed_prefetch(side_for_device(), (hipStream_t)stream, d, p, x, ws, B));
@@ -840,8 +858,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
       MVH_REQUIRE(dfr, "vae_backward: the patch kernel did not defer its weight-gradient reduction");
       ++red.n;
       if (i == n - 1 && use_tstack) {
-        if (pf && pf->pending && pf->x == x && pf->stream == sstream) {
-          ev_tstack = pf->done;      // built ahead of the forward (mvh_vae_backward_prefetch)
+        if (pf && pf->pending && pf->x == x && (pf->stream == sstream || !pf->stream)) {
+          ev_tstack = (!pf->stream && pf->fwd == main) ? nullptr : pf->done;   // built ahead (prefetch), or by the forward itself
         } else {
           TRY(flush_dw(false));
           MVH_HIP(hipEventRecord(side->ev[ev], main));
@@ -863,8 +881,8 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
                      G[ix.decW(i)], G[ix.decB(i)], p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, BITS(p.decBits[i]), io,
                      p.dwPartDec[i], p.dwPartBytesDec[i], nullptr, nullptr, nullptr, bf ? nullptr : TX(p.txDec[i])));
     if (i == n - 1 && use_tstack) {
-      if (pf && pf->pending && pf->x == x && pf->stream == sstream) {
-        ev_tstack = pf->done;      // built ahead of the forward (mvh_vae_backward_prefetch)
+      if (pf && pf->pending && pf->x == x && (pf->stream == sstream || !pf->stream)) {
+        ev_tstack = (!pf->stream && pf->fwd == main) ? nullptr : pf->done;   // built ahead (prefetch), or by the forward itself
       } else {
         // T_k x of encoder layer 0 at its pooled rows: 64 workgroups on the side lane behind the (chip-filling)
         // dW above, i.e. while the main chain runs its small-level kernels; consumed at the very end

@@ -598,6 +598,13 @@ class NativeStep:
                 if got is not None:
                     self._patch_keep.append(got)
                     d.lap[i].patch = d.lap_t[i].patch = ctypes.addressof(got[0])
+        # ... and the first layer (<= 4 -> 16 channels in front of its one-hot downsampling): the plan whose pooling rows are
+        # that operator's hangs off the desc's copy of the operator (k_patch_enc0; either storage)
+        if n >= 1 and net.filters[0] <= 4 and net.filters[1] == 16:
+            got = topology.patch_plan(net._lap[0], int(net.K[0]) - 1, down_op=net._down[0])
+            if got is not None and got[0].n_pool_rows == net._down[0].fwd.n_rows:
+                self._patch_keep.append(got)
+                d.down[0].patch = ctypes.addressof(got[0])
         self.desc = d
         L = lib()
         self.params = [p for _, p in net.named_parameters()]

@@ -219,30 +219,37 @@ def laplacian(edge_index, norm, num_nodes):
     return hit[0]
 
 
-def patch_plan(lap_op, n_rings, up_op=None):
+def patch_plan(lap_op, n_rings, up_op=None, down_op=None):
     """Vertex-patch plan (meshvae_hip/patches.py, csrc/cheb_patch.hip) of a level's Laplacian, uploaded:
     -> (PatchPlanStruct, keep-alive) or None when the level is not one the patch kernels take (2 049 .. 5 119 vertices,
     normalised symmetric Laplacian, at most 8 neighbours, a cut whose largest patch fits the LDS).  up_op: the level's
-    un-pooling Operator (coarse -> this level); its transpose's rows are then formed inside the backward kernel."""
+    un-pooling Operator (coarse -> this level); its transpose's rows are then formed inside the backward kernel.
+    down_op: the level's one-hot downsampling Operator (this level -> coarse) instead: its rows are the pooled rows the
+    first layer's kernel (k_patch_enc0) contracts and stores."""
     import ctypes
     from . import patches
     csr = lap_op.fwd
     need = CSR_NORMALIZED_LAPLACIAN | CSR_SYMMETRIC
     if (csr.flags & need) != need or not (2048 < csr.n_rows + 1 <= 5120) or csr.max_row_nnz > patches.MAX_DEG or n_rings < 0:
         return None
+    assert up_op is None or down_op is None
     cache = lap_op.__dict__.setdefault("_patch_plans", {})
-    key = (int(n_rings), None if up_op is None else id(up_op))
+    key = (int(n_rings), None if up_op is None else id(up_op), None if down_op is None else id(down_op))
     if key not in cache:
         rowptr = csr.rowptr.cpu().numpy().astype(np.int64)
         rows = np.repeat(np.arange(csr.n_rows), rowptr[1:] - rowptr[:-1])
         cols = csr.col.cpu().numpy().astype(np.int64)
         pool_t, pool_rowptr = None, None
+        t = None
         if up_op is not None and up_op.bwd.n_cols == csr.n_rows:
             t = up_op.bwd                                     # U^T: rows = coarse vertices, columns = this level
+        elif down_op is not None and down_op.fwd.n_cols == csr.n_rows:
+            t = down_op.fwd                                   # D: rows = coarse vertices, columns = this level
+        if t is not None:
             pool_t = (t.rowptr.cpu().numpy().astype(np.int64), t.col.cpu().numpy().astype(np.int64), t.val.cpu().numpy())
             pool_rowptr = t.rowptr
         plan = patches.build_plan(csr.n_rows, rows, cols, int(n_rings), pool_t)
-        cache[key] = None if plan is None else plan.device(csr.rowptr.device, pool_rowptr) + (plan, up_op)
+        cache[key] = None if plan is None else plan.device(csr.rowptr.device, pool_rowptr) + (plan, up_op if up_op is not None else down_op)
     return cache[key]
 
 

@@ -439,7 +439,9 @@ def test_bf16_step_against_fp32_kernels_with_emulated_storage(which, B):
     eps = torch.randn(B, 16, generator=g).to(dev)
     net = _model(which, dev).train()
     net._prepare()
-    with debug_switch("no_l0h", 1):
+    # (... and the first layer on the kernel the module-level op runs: the step's own first-layer kernel, k_patch_enc0, sums
+    #  in another order -- it is held against this form by tests/test_gpu_patch.py::test_first_layer_patch_kernel_in_the_step)
+    with debug_switch("no_l0h", 1), debug_switch("no_enc0_patch", 1):
         nat = NativeStep(net, B, storage="bf16")
         loss, _, recon, (_, _, z_), _ = nat.forward_backward(x, x, y, eps=eps, drop_u=None)
         torch.cuda.synchronize()

@@ -759,12 +759,12 @@ def test_round3_forms_against_their_debug_switches(B):
     y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
     eps = torch.randn(B, 16, generator=g).to(dev)
 
-    def run(switch):
+    def run(switch, slab_first_layer=False):
         torch.manual_seed(666)
         net = cheb_VAE(3, dict(CFG_5K), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
         key, val = switch if switch else ("keep_enc_out", 0)
         # (l0_lane_any: the level-0 lane at these batch sizes too -- by default it is taken for 56 < B <= 64 only)
-        with debug_switch("l0_lane_any", 1), debug_switch(key, val):
+        with debug_switch("l0_lane_any", 1), debug_switch("no_enc0_patch", 1 if slab_first_layer else 0), debug_switch(key, val):
             nat = NativeStep(net, B)
             drop_u = torch.rand(B * nat.u_cols, generator=torch.Generator().manual_seed(9)).to(dev)
             loss, corr, recon, (kld, rec, z_), yh = nat.forward_backward(x, x.double(), y, eps=eps, drop_u=drop_u)
@@ -772,7 +772,14 @@ def test_round3_forms_against_their_debug_switches(B):
         return (dict(loss=loss.clone(), recon=recon.clone(), kld=kld.clone(), rec=rec.clone(), z=z_.clone(), yh=yh.clone()),
                 {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     base_out, base_g = run(None)
-    for switch, exact in ((("keep_enc_out", 1), True), (("no_final_fuse", 1), True), (("tstack_tall", 1), True),
+    # keep_enc_out and tstack_tall are forms of the SLAB first layer (cheb_lds.hip + k_cheb_tstack; since round 5 the step
+    # runs k_patch_enc0 there, which has neither): they are held against that form (debug switch no_enc0_patch)
+    slab_out, slab_g = run(None, slab_first_layer=True)
+    for switch in (("keep_enc_out", 1), ("tstack_tall", 1)):
+        out, grads = run(switch, slab_first_layer=True)
+        assert all(torch.equal(out[k], slab_out[k]) for k in slab_out), switch
+        assert all(torch.equal(grads[k], slab_g[k]) for k in slab_g), switch
+    for switch, exact in ((("no_final_fuse", 1), True),
                           (("fork_small", 0), True),        # (every coarse layer's weight gradient behind a fork of its own)
                           (("l0_lane", 0), True),           # (the 5k level's weight gradient as ONE launch on the conv lane)
                           (("l0_lane", 3), True),           # (... in three part-batch launches: 24 + 24 + 16 meshes)

@@ -145,3 +145,55 @@ def test_plan_with_pooling_rows_matches_spmm_of_plain_dx():
     torch.testing.assert_close(dx_a, dx_c, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(dw_a, dw_c, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db_a, db_c, rtol=1e-4, atol=1e-4)
+
+
+def _step_5k(switches, B=5, storage="f32", seed=21):
+    """one NativeStep forward + backward of the 5k model under debug switches -> (loss, recon, z, gradients)"""
+    import contextlib
+    import os
+    import sys
+    import meshvae_hip
+    from conftest import CFG_5K
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    D, U, A, nn_ = load_topology(os.path.join(root, "tests", "golden", "topology_5k.npz"), dev)
+    torch.manual_seed(666)
+    net = cheb_VAE(3, dict(CFG_5K, dropout=0.0), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4998, 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, net.z, generator=g).to(dev)
+    with contextlib.ExitStack() as es:
+        for k, v in switches.items():
+            es.enter_context(meshvae_hip.debug_switch(k, v))
+        nat = NativeStep(net, B, storage=storage)
+        outs = []
+        for _ in range(2):          # (twice: the second forward reuses the workspace whose stack the first backward consumed)
+            loss, _, recon, (_, _, z_), _ = nat.forward_backward(x, x, y, eps=eps, drop_u=None)
+            torch.cuda.synchronize()
+            outs.append((float(loss), recon.clone(), z_.clone(),
+                         {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert len(outs[0][3]) > 10 and all(torch.equal(outs[0][3][k], outs[1][3][k]) for k in outs[0][3])
+    return outs[1]
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_first_layer_patch_kernel_in_the_step(storage):
+    """k_patch_enc0 (the 3 -> 16 layer's recurrence on the input side, pooled rows + sign bytes + the weight gradient's
+    T_k stack out of one launch) against the slab kernel + k_cheb_tstack it replaces in the step (debug switch
+    no_enc0_patch): the same step to fp32 reassociation -- and not bitwise, so the kernel really ran.  The first layer's
+    weight gradient is the product of exactly the two things the kernel hands over (stack and sign bytes)."""
+    a = _step_5k({}, storage=storage)
+    b = _step_5k({"no_enc0_patch": 1}, storage=storage)
+    tol = 2e-5 if storage == "f32" else 2e-2      # (bf16 storage: a stored value may land on the other side of a rounding boundary)
+    assert abs(a[0] - b[0]) <= (1e-6 if storage == "f32" else 1e-3) * abs(b[0])
+    scale = float(b[1].abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= tol * scale
+    assert not all(torch.equal(a[3][k], b[3][k]) for k in a[3]), "the switch changed nothing: the patch kernel did not run"
+    for k in b[3]:
+        rel = float((a[3][k] - b[3][k]).norm() / b[3][k].norm().clamp_min(1e-20))
+        assert rel < (1e-4 if storage == "f32" else 5e-2), (k, rel)
