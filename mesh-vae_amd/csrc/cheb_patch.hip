@@ -758,53 +758,74 @@ k_patch_enc0(const float* __restrict__ p_x, const float* __restrict__ p_W, const
   float* coefv = reinterpret_cast<float*>(smem + (size_t)(rows16 + 1) * kRowB);   // [rows16]
   float* wl = coefv + rows16;                                                     // [K][4][16], rows >= cin zero
   MVH_STAMPX(0);
-  for (int i = tid; i < rows16; i += THREADS) {
-    *reinterpret_cast<uint4*>(smem + (size_t)i * kRowB + 64) = reinterpret_cast<const uint4*>(p_ell)[o + i];
-    const float deg = (float)((p_pinfo[o + i] >> 16) & 255u);
-    coefv[i] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
-  }
   if (tid == 0) *reinterpret_cast<float4*>(smem + (size_t)rows16 * kRowB) = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < K * 64; i += THREADS) {
-    const int k = i >> 6, ci = (i >> 4) & 3, co = i & 15;
-    wl[i] = ci < a.cin ? p_W[(k * a.cin + ci) * 16 + co] : 0.f;
-  }
   const int n0 = c[1 + min(a.R, K - 1)];           // rows whose u_0 somebody needs
   const float* xb = p_x + (long long)mesh * a.x_bs * a.cin;
+  // the pooled rows of this patch: lane task (row i, output quad q); a dead task reads the zero row.  One entry per row
+  // (a selection operator): entry ebase + i.
+  const int r0 = p_prow_off[pt], nrow = p_prow_off[pt + 1] - r0;
+  const int ebase = p_prow_ptr[r0 + pt];
+  const int n_sel = a.n_pool_rows;
+  // every load of the prologue in two rounds of independent loads (indices clamped, no branch around a load): first the
+  // row words and the tasks' (column, row id), then what they point to -- x rows and the selected vertices' row words.
+  // (Written slot by slot behind their tests these were ten dependent round trips: 7.7k of the kernel's 28k cycles.)
+  uint32_t info[SLOTS];
+  uint4 ellw[SLOTS];
+  int lc[TS], grow[TS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int vi = o + min(s * THREADS + tid, rows16 - 1);
+    info[s] = p_pinfo[vi];
+    ellw[s] = reinterpret_cast<const uint4*>(p_ell)[vi];
+  }
+  float wv = 0.f;                  // this thread's weight of the LDS copy [K][4][16] (rows >= cin zero)
+  if (tid < K * 64) {
+    const int k = tid >> 6, ci = (tid >> 4) & 3, co = tid & 15;
+    wv = p_W[(k * a.cin + min(ci, a.cin - 1)) * 16 + co];
+    if (ci >= a.cin) wv = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    const int i = (j * THREADS + tid) >> 2;
+    const bool live = i < nrow;
+    lc[j] = p_pcol[live ? ebase + i : 0];
+    grow[j] = p_prow_gid[live ? r0 + i : 0];
+  }
+  float xr[SLOTS][4];
+  uint32_t tinfo[TS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const float* xp = xb + (long long)(info[s] & 0xffffu) * a.cin;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xr[s][t] = xp[t < a.cin ? t : 0];
+  }
+#pragma unroll
+  for (int j = 0; j < TS; ++j) tinfo[j] = p_pinfo[o + lc[j]];
   float4 st[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int v = s * THREADS + tid;
     st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v < n0) {
-      const uint32_t info = p_pinfo[o + v];
-      const float deg = (float)((info >> 16) & 255u);
-      if ((info >> 24 & 15u) != 15u) {
-        const float sc = deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f;
-        const float* xr = xb + (long long)(info & 0xffffu) * a.cin;
-        r.x = xr[0] * sc;
-        if (a.cin > 1) r.y = xr[1] * sc;
-        if (a.cin > 2) r.z = xr[2] * sc;
-        if (a.cin > 3) r.w = xr[3] * sc;
-      }
+    const float deg = (float)((info[s] >> 16) & 255u);
+    const bool use = v < n0 && (info[s] >> 24 & 15u) != 15u;
+    const float sc = use ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    const float4 r = make_float4(xr[s][0] * sc, a.cin > 1 ? xr[s][1] * sc : 0.f, a.cin > 2 ? xr[s][2] * sc : 0.f,
+                                 a.cin > 3 ? xr[s][3] * sc : 0.f);
+    if (v < rows16) {
+      *reinterpret_cast<float4*>(smem + (size_t)v * kRowB) = r;
+      *reinterpret_cast<uint4*>(smem + (size_t)v * kRowB + 64) = ellw[s];
+      coefv[v] = deg > 0.f ? -2.0f * __builtin_amdgcn_rcpf(deg) : 0.f;
     }
-    if (v < rows16) *reinterpret_cast<float4*>(smem + (size_t)v * kRowB) = r;
   }
-  // the pooled rows of this patch: lane task (row i, output quad q); a dead task reads the zero row
-  const int r0 = p_prow_off[pt], nrow = p_prow_off[pt + 1] - r0;
-  const int* __restrict__ rp = p_prow_ptr + r0 + pt;
-  const int n_sel = a.n_pool_rows;
-  int lc[TS], grow[TS];
+  if (tid < K * 64) wl[tid] = wv;
   float is[TS];
   float4 acc[TS];
 #pragma unroll
   for (int j = 0; j < TS; ++j) {
-    const int t = j * THREADS + tid, i = t >> 2;
-    const bool live = i < nrow;
-    lc[j] = live ? p_pcol[rp[i]] : rows16;
-    grow[j] = live ? p_prow_gid[r0 + i] : -1;
-    const float deg = live ? (float)((p_pinfo[o + lc[j]] >> 16) & 255u) : 0.f;
+    const bool live = ((j * THREADS + tid) >> 2) < nrow;
+    const float deg = (float)((tinfo[j] >> 16) & 255u);
     is[j] = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
+    if (!live) { lc[j] = rows16; grow[j] = -1; }
     acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int q = tid & 3;
@@ -819,11 +840,15 @@ k_patch_enc0(const float* __restrict__ p_x, const float* __restrict__ p_W, const
       const float4 w0 = *reinterpret_cast<const float4*>(wl + (k * 4 + 0) * 16 + 4 * q);
       const float4 w1 = *reinterpret_cast<const float4*>(wl + (k * 4 + 1) * 16 + 4 * q);
       const float4 w2 = *reinterpret_cast<const float4*>(wl + (k * 4 + 2) * 16 + 4 * q);
-      const float4 w3 = *reinterpret_cast<const float4*>(wl + (k * 4 + 3) * 16 + 4 * q);
-      acc[j].x = fmaf(T.w, w3.x, fmaf(T.z, w2.x, fmaf(T.y, w1.x, fmaf(T.x, w0.x, acc[j].x))));
-      acc[j].y = fmaf(T.w, w3.y, fmaf(T.z, w2.y, fmaf(T.y, w1.y, fmaf(T.x, w0.y, acc[j].y))));
-      acc[j].z = fmaf(T.w, w3.z, fmaf(T.z, w2.z, fmaf(T.y, w1.z, fmaf(T.x, w0.z, acc[j].z))));
-      acc[j].w = fmaf(T.w, w3.w, fmaf(T.z, w2.w, fmaf(T.y, w1.w, fmaf(T.x, w0.w, acc[j].w))));
+      acc[j].x = fmaf(T.z, w2.x, fmaf(T.y, w1.x, fmaf(T.x, w0.x, acc[j].x)));
+      acc[j].y = fmaf(T.z, w2.y, fmaf(T.y, w1.y, fmaf(T.x, w0.y, acc[j].y)));
+      acc[j].z = fmaf(T.z, w2.z, fmaf(T.y, w1.z, fmaf(T.x, w0.z, acc[j].z)));
+      acc[j].w = fmaf(T.z, w2.w, fmaf(T.y, w1.w, fmaf(T.x, w0.w, acc[j].w)));
+      if (a.cin > 3) {          // (uniform; the mesh input has three channels)
+        const float4 w3 = *reinterpret_cast<const float4*>(wl + (k * 4 + 3) * 16 + 4 * q);
+        acc[j].x = fmaf(T.w, w3.x, acc[j].x); acc[j].y = fmaf(T.w, w3.y, acc[j].y);
+        acc[j].z = fmaf(T.w, w3.z, acc[j].z); acc[j].w = fmaf(T.w, w3.w, acc[j].w);
+      }
     }
   };
   MVH_STAMPX(1);
@@ -869,7 +894,7 @@ k_patch_enc0(const float* __restrict__ p_x, const float* __restrict__ p_W, const
     if (a.act == MVH_ACT_RELU) { r0v = fmaxf(r0v, 0.f); r1v = fmaxf(r1v, 0.f); r2v = fmaxf(r2v, 0.f); r3v = fmaxf(r3v, 0.f); }
     store4_any(p_pooled, ((long long)mesh * n_sel + grow[j]) * 16 + 4 * q, a.out_bf16 != 0, r0v, r1v, r2v, r3v);
     if (p_bits) {
-      const long long vrow = (long long)mesh * a.N + (p_pinfo[o + lc[j]] & 0xffffu);
+      const long long vrow = (long long)mesh * a.N + (tinfo[j] & 0xffffu);
       p_bits[vrow * 4 + q] = (uint8_t)((r0v > 0.f ? 1 : 0) | (r1v > 0.f ? 2 : 0) | (r2v > 0.f ? 4 : 0) | (r3v > 0.f ? 8 : 0));
     }
   }
@@ -988,7 +1013,7 @@ static size_t enc0_lds_bytes(const mvh_patch_plan_t* pl, int K) {
 }
 
 bool patch_enc0_eligible(const mvh_csr_t* lap, const mvh_csr_t* down, int N, int Cin, int Cout, int K) {
-  if (dbg().no_patch || dbg().no_enc0_patch || dbg().force_generic) return false;
+  if (dbg().no_patch == 1 || dbg().no_enc0_patch || dbg().force_generic) return false;   // (no_patch = 2: the 16 -> 16 kernels only, diagnostics)
   const mvh_patch_plan_t* pl = down ? down->patch : nullptr;
   if (!pl || !lap || Cin < 1 || Cin > 4 || Cout != 16 || K < 1 || K > 12) return false;
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;

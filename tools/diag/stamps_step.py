@@ -12,7 +12,10 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--enc0", action="store_true", help="the first layer's kernel (k_patch_enc0) instead: the 16 -> 16 patch kernels are switched off (no_patch=2) so that its stamps are the last ones written")
 args = ap.parse_args()
+if args.enc0:
+    os.environ["MESHVAE_DEBUG"] = "no_patch=2"
 import bench
 from meshvae_hip import lib
 from meshvae_hip.engine import TrainStep
@@ -34,7 +37,7 @@ torch.cuda.synchronize()
 buf = np.zeros(512 * 16 * 32, dtype=np.uint64)
 assert rd(buf.ctypes.data, 0) == 0
 t = buf.reshape(512, 16, 32).astype(np.float64)
-for name, waves in (("recurrence waves 0-7", slice(0, 8)), ("matrix waves 8-15", slice(8, 16))):
+for name, waves in ((("all waves", slice(0, 16)),) if args.enc0 else (("recurrence waves 0-7", slice(0, 8)), ("matrix waves 8-15", slice(8, 16)))):
     tt = t[:, waves, :]
     used = tt[:, :, 0] > 0
     slots = [s for s in range(32) if (tt[:, :, s][used] > 0).all()]
