@@ -289,12 +289,12 @@ def test_b64_equals_eight_b8_runs_bitwise(which):
             assert torch.equal(part[k], full[k][sl]), (k, c)
 
 
-@pytest.mark.parametrize("B", [1, 7, 33, 63, 65])
+@pytest.mark.parametrize("B", [1, 7, 33, 63, 65, 96, 128])
 def test_ragged_batch_sizes_match_oracle(B):
     """Batches that are not multiples of the 8 XCDs (the block -> mesh maps end in `if (mesh >= B) return`), a single
-    mesh, and one mesh more than the benchmarked batch: the whole fp32 step against the oracle, all meshes, same bars.
-    B = 63 takes the level-0 lane (56 < B <= 64: the 5k level's weight gradient in two part-batch launches of 32 + 31
-    meshes, `DwDims::mesh0`), B = 33 and 65 are single launches again (132 and 260 workgroups)."""
+    mesh, one mesh more than the benchmarked batch, and batches of one and a half and two rounds of the 5k level's
+    one-workgroup-per-CU kernels (96, 128 meshes = 384, 512 patch workgroups): the whole fp32 step against the oracle,
+    all meshes, same bars."""
     dev = _dev()
     net = _build(CFG_5K, "topology_5k.npz", dev).train()
     x, y, eps, g = _inputs(net, B, seed=40 + B)
