@@ -159,7 +159,8 @@ def lds_kernel_name(kind, lap, N, Cin, Cout, half=False):
     path (split path, stack pipeline)."""
     pw = 8 if lap.fwd.ell_pairs > 4 else 4
     pp = patch_plan_of(lap)
-    if pp is not None and not half and Cin == 16 and Cout == 16 and kind in ("fwd", "dX+dW"):
+    # (bf16 storage: the backward only -- the forward stays on the bf16 matrix-pipe kernel k_cheb_l0h)
+    if pp is not None and Cin == 16 and Cout == 16 and (kind == "dX+dW" or (kind == "fwd" and not half)):
         # vertex-patch kernels (csrc/cheb_patch.hip: FwdCfg / BwdCfg; the SU variant needs that many core tiles per wave)
         tiles = pp.min_core // 16
         if kind == "fwd":
@@ -228,7 +229,7 @@ def conv_ops(net, B, dev, dtype="f32"):
     keep_plans = []
     for label, lap, N, Cin, Cout, K, relu, has_dx in layers:
         half = dtype == "bf16" and Cin % 4 == 0 and Cout % 4 == 0
-        if label.startswith("dec") and not half and Cin == 16 and Cout == 16 and patch_plan_of(lap) is not None:
+        if label.startswith("dec") and Cin == 16 and Cout == 16 and patch_plan_of(lap) is not None:
             from meshvae_hip import topology
             lvl = [i for i in range(n) if net._lap[i] is lap][0]
             got = topology.patch_plan(lap, int(K) - 1, net._up[lvl])

@@ -1255,7 +1255,11 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
     return MVH_OK;
   }
   // vertex-patch plan on this level (cheb_patch.hip): dX (+ its pooling) and the dW / db partial tiles from ONE launch
-  if (!dout_pool && !tx_saved && !bf && !dbg().no_patch_bwd && patch_eligible(lap_t, N, Cin, Cout, K) &&
+  // (bf16 storage: x, dout and dx all bf16 -- the whole step's mode --, fp32 arithmetic; the debug switch no_l0h, which
+  //  selects the general kernels for the bf16 rows of this level, switches this form off as well)
+  const bool bf_patch = io.x && io.dout && !io.x_map && (dx == nullptr || (io.dx && (!dx_pooled || io.dx_pooled))) && !dbg().no_l0h &&
+                        !dbg().no_patch_bf16;
+  if (!dout_pool && !tx_saved && (!bf || bf_patch) && !dbg().no_patch_bwd && patch_eligible(lap_t, N, Cin, Cout, K) &&
       (act != MVH_ACT_RELU || out_bits) &&
       (((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dx_pooled | (uintptr_t)W | (uintptr_t)partial |
         (uintptr_t)defer_part) & 15) == 0) {
@@ -1268,7 +1272,7 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
       DwReduceEntry e{};
       if (int rc = launch_patch_bwd(st, lap_t, x, W, dout, act == MVH_ACT_RELU ? out_bits : nullptr, io.src3_g, io.src3_w,
                                     io.src3_n, pooled ? dx_pooled : dx, pooled, part, pbytes, &e, dW, db, B, N, K, io.x_map,
-                                    io.x_bs)) return rc;
+                                    io.x_bs, io.x, io.dout, pooled ? io.dx_pooled : io.dx)) return rc;
       if (dW) {
         if (defer) {
           *defer = e;
@@ -1280,7 +1284,10 @@ int mvh::cheb_conv_bwd_impl(hipStream_t stream, const mvh_csr_t* lap, const mvh_
           if (int rc = launch_dw_reduce_all(st, t)) return rc;
         }
       }
-      if (want_pool && !pooled) return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+      if (want_pool && !pooled) {
+        MVH_REQUIRE(!bf, "cheb_conv_bwd: bf16 storage pools dx inside the patch kernel only");
+        return launch_spmm(st, dx_pool_t, dx, dx_pooled, nullptr, nullptr, 1.f, 0.f, B, Cin, true);
+      }
       return MVH_OK;
     }
   }

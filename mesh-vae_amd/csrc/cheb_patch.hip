@@ -51,7 +51,8 @@ struct PatchDims {
   int pool_lds;         // the pooling entries of every patch fit the LDS behind its core rows
   int x_bs;             // rows per mesh of the layer input x (N, or the mesh stride of a strided view in rows)
   int cin;              // k_patch_enc0: input channels (<= 4)
-  int out_bf16;         // k_patch_enc0: the pooled output rows are stored as bf16 (bf16.hpp)
+  int out_bf16;         // k_patch_enc0: the pooled output rows are stored as bf16 (bf16.hpp); k_patch_bwd: dx / its pooled rows
+  int x_bf16, dout_bf16;  // k_patch_bwd on bf16 STORAGE: x and the stored dout rows are bf16 tensors (fp32 arithmetic throughout)
 };
 
 // float4 sums / fused multiply-adds as TWO packed instructions (v_pk_add_f32 / v_pk_fma_f32: two fp32 lanes per issue slot,
@@ -415,7 +416,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         }
       } else {
 #pragma unroll
-        for (int s = 0; s < RS; ++s) st[s] = *reinterpret_cast<const float4*>(p_dout + (mrow + (inf[s] & 0xffffu)) * 16 + 4 * q);
+        for (int s = 0; s < RS; ++s) st[s] = load4_any(p_dout, (mrow + (inf[s] & 0xffffu)) * 16 + 4 * q, a.dout_bf16 != 0);
       }
       uint32_t mb[RS];
 #pragma unroll
@@ -461,7 +462,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
             const float sc = deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f;
             const float* gr = p_g3 + (mrow + gid) * 3;
             const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
-            float4 lz, dv = *reinterpret_cast<const float4*>(p_dout + (mrow + gid) * 16 + 4 * q);
+            float4 lz, dv = load4_any(p_dout, (mrow + gid) * 16 + 4 * q, a.dout_bf16 != 0);
             lz.x = fmaf(g2, w3r[0][2], fmaf(g1, w3r[0][1], g0 * w3r[0][0]));
             lz.y = fmaf(g2, w3r[1][2], fmaf(g1, w3r[1][1], g0 * w3r[1][0]));
             lz.z = fmaf(g2, w3r[2][2], fmaf(g1, w3r[2][1], g0 * w3r[2][0]));
@@ -569,7 +570,10 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
     float xa[GS];
     float wa[4];
     auto load_w = [&](int k) {   // A = W_k^T: [c_in = vi][c_out = 4 q + s]
-      const float4 t = *reinterpret_cast<const float4*>(p_W + k * 256 + vi * 16 + 4 * q);
+      float4 t = *reinterpret_cast<const float4*>(p_W + k * 256 + vi * 16 + 4 * q);
+      // bf16 storage: the forward of this layer (k_cheb_l0h) multiplies by a bf16 COPY of the weights; dX is the gradient
+      // of THAT function, so it takes the same rounded weights (one RNE rounding per element, bf16.hpp)
+      if (a.x_bf16) t = bf16_unpack4(bf16_pack4(t.x, t.y, t.z, t.w));
       wa[0] = t.x; wa[1] = t.y; wa[2] = t.z; wa[3] = t.w;
     };
     // A operand of the weight gradient: D^1/2 x of the exclusive vertices, [c_in = vi][vertex 4 g + q]; 0 elsewhere
@@ -579,7 +583,11 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
 #pragma unroll
       for (int gs = 0; gs < GS; ++gs) xinf[gs] = p_pinfo[o + min(4 * (gs * NWD + wd) + q, rows16 - 1)];
       const float* xb = p_x + (long long)mesh * a.x_bs * 16 + vi;
-      if (p_xmap) {
+      if (a.x_bf16) {          // (bf16 storage: never with a row map)
+        const long long xo = (long long)mesh * a.x_bs * 16 + vi;
+#pragma unroll
+        for (int gs = 0; gs < GS; ++gs) xa[gs] = load1_any(p_x, xo + (long long)(xinf[gs] & 0xffffu) * 16, true);
+      } else if (p_xmap) {
 #pragma unroll
         for (int gs = 0; gs < GS; ++gs) xa[gs] = xb[(long long)p_xmap[xinf[gs] & 0xffffu] * 16];
       } else {
@@ -670,8 +678,8 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
           const uint32_t info = p_pinfo[o + v];
           const float deg = (float)((info >> 16) & 255u);
           const float is = deg > 0.f ? __builtin_sqrtf(deg) : 1.0f;
-          *reinterpret_cast<float4*>(p_dx + (mrow + (info & 0xffffu)) * 16 + 4 * q) =
-              make_float4(acc[i][0] * is, acc[i][1] * is, acc[i][2] * is, acc[i][3] * is);
+          store4_any(p_dx, (mrow + (info & 0xffffu)) * 16 + 4 * q, a.out_bf16 != 0, acc[i][0] * is, acc[i][1] * is,
+                     acc[i][2] * is, acc[i][3] * is);
         }
       }
       return;
@@ -722,7 +730,7 @@ k_patch_bwd(const float* __restrict__ p_dout, const uint8_t* __restrict__ p_mbit
         sacc.w = __fadd_rn(sacc.w, __fmul_rn(wv[t], n[t].w));
       }
     }
-    *reinterpret_cast<float4*>(p_dx + ((long long)mesh * a.n_pool_rows + grow) * 16 + 4 * qq) = sacc;
+    store4_any(p_dx, ((long long)mesh * a.n_pool_rows + grow) * 16 + 4 * qq, a.out_bf16 != 0, sacc.x, sacc.y, sacc.z, sacc.w);
   }
   MVH_STAMPX(28);
 }
@@ -967,10 +975,11 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
                      float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K,
-                     const int32_t* x_map, int x_bs) {
+                     const int32_t* x_map, int x_bs, bool x_bf16, bool dout_bf16, bool dx_bf16) {
   const mvh_patch_plan_t* pl = lap->patch;
   MVH_REQUIRE((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)W | (uintptr_t)part) & 15) == 0,
               "patch_bwd: tensors must be 16-byte aligned");
+  MVH_REQUIRE(!(x_bf16 && x_map), "patch_bwd: a strided x is an fp32 tensor");
   MVH_REQUIRE(!pooled || pl->n_pool_rows > 0, "patch_bwd: the plan carries no pooling rows");
   MVH_REQUIRE(dx || dW, "patch_bwd: nothing to compute");
   MVH_REQUIRE(cfg_fits(pl), "patch_bwd: the plan does not fit the kernel's register arrays");
@@ -978,6 +987,7 @@ int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = 0;
   d.x_bs = x_map ? x_bs : N;
   d.n_pool_rows = pooled ? pl->n_pool_rows : 0;
+  d.x_bf16 = x_bf16 ? 1 : 0; d.dout_bf16 = dout_bf16 ? 1 : 0; d.out_bf16 = dx_bf16 ? 1 : 0;
   d.src3_n = g3 ? src3_n : -1;
   d.n_part = B * pl->n_patches;
   d.has_dw = dW ? 1 : 0; d.has_dx = dx ? 1 : 0;

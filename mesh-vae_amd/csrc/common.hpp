@@ -132,6 +132,7 @@ struct DebugCfg {
   int big_half_ids = 0;    // TIMING ONLY, results invalid: k_cheb_big fetches 8 of the 16 id bytes per vertex and order (what would 1-byte ids buy?)
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
+  int no_patch_bf16 = 0;   // 1: bf16 storage keeps the matrix-pipe slab kernels (cheb_l0h.hip) for the 5k level's backward
   int no_enc0_patch = 0;   // 1: the first layer's forward stays on the slab kernel and the backward builds its stack (k_cheb_tstack)
   int patch_flush_first = 1;   // the step forks the weight-gradient items queued so far (the final layer's) BEFORE a patch backward
                                // launch, so that they run beside it (MEASURED: 458 against 485 us per step; 0: behind it)
@@ -314,7 +315,8 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
                      float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K,
-                     const int32_t* x_map = nullptr /* ConvIO::x_map: strided layer input (the dW operand) */, int x_bs = 0);
+                     const int32_t* x_map = nullptr /* ConvIO::x_map: strided layer input (the dW operand) */, int x_bs = 0,
+                     bool x_bf16 = false, bool dout_bf16 = false, bool dx_bf16 = false /* bf16 STORAGE of x / dout / dx */);
 // LDS-resident dW/db (cheb_dw_lds.hip): `part` is scratch of cheb_dw_lds_ws_bytes()
 size_t cheb_dw_lds_ws_bytes(int B, int N, int Cin, int Cout, int K);
 int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* dout, const float* out_mask,

@@ -592,7 +592,10 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
   // dout W_eff^T off its 20-vertex block -- 3 numbers per vertex -- so it writes ONLY the block's rows and the stage's dX /
   // dW kernels rebuild the other rows while they load them (no k_gstack_rows launch on the main chain, 64 -> 12 bytes
   // per vertex read by each of the two chip-filling kernels, 20 MB less written).  5k-class fp32 models only.
-  const bool lazy3 = !bf && !dbg().no_src3 && !dbg().force_generic && !dbg().l0_wide && !dbg().dw_tie_x && !dbg().no_side &&
+  // (bf16 storage: when the stage's backward is the vertex-patch kernel, which reads lazy rows in either storage mode)
+  const bool bf_lazy_ok = bf && !dbg().no_l0h && !dbg().no_patch_bf16 && !dbg().no_patch_bwd && n >= 1 &&
+                          patch_eligible(&d->lap_t[0], p.Nn[0], p.f[2], p.f[1], d->K[n - 1]);
+  const bool lazy3 = (!bf || bf_lazy_ok) && !dbg().no_src3 && !dbg().force_generic && !dbg().l0_wide && !dbg().dw_tie_x && !dbg().no_side &&
                      p.Nn[0] + 1 > 2048 && p.Nn[0] + 1 <= 5120 && p.f[1] == 16 && p.f[2] == 16 && p.F0 == 3 &&
                      conv_split_eligible(&d->lap[n], p.Nn[0], p.f[1], p.f[0], d->K[n]) &&
                      conv_split_eligible(&d->lap_t[n], p.Nn[0], p.f[1], p.f[0], d->K[n]) && d->lap[n].n_active <= 512 &&
@@ -846,7 +849,9 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     // A level with a vertex-patch plan (cheb_patch.hip; the 5k level's 16 -> 16 stage): dX, its U^T pooling and the dW / db
     // partial tiles come out of ONE launch on the main chain -- nothing of this stage on the weight-gradient lanes (the
     // slab form: a 43 us dX launch on the chain + two 71 us half-batch dW launches that hold 128 CUs each on the dense lane)
-    if (!bf && !dx_first && !dbg().no_patch_bwd && BITS(p.decBits[i]) && red.n < (int)(sizeof(red.e) / sizeof(red.e[0])) &&
+    // (bf16 storage: the same kernel with bf16 loads / stores -- instead of k_cheb_l0h's dX on the chain + k_cheb_dw_l0h twice on a
+    //  lane; the debug switch no_l0h keeps the general kernels there)
+    if ((!bf || (!dbg().no_l0h && !dbg().no_patch_bf16)) && !dx_first && !dbg().no_patch_bwd && BITS(p.decBits[i]) && red.n < (int)(sizeof(red.e) / sizeof(red.e[0])) &&
         patch_eligible(&d->lap_t[lvl], p.Nn[lvl], cin, cout, d->K[i]) &&
         p.dwPartBytesDec[i] >= patch_part_bytes(&d->lap_t[lvl], B, d->K[i])) {
       if (dbg().patch_flush_first) TRY(flush_dw(false));   // (queued items of the final layer start beside this launch, not behind it)

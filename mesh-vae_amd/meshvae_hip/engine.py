@@ -593,7 +593,7 @@ class NativeStep:
         from . import topology
         for i in range(n):
             j = n - 1 - i                                    # decoder stage of level i: filters[i + 2] -> filters[i + 1]
-            if storage != "bf16" and net.filters[i + 1] == 16 and net.filters[i + 2] == 16:
+            if net.filters[i + 1] == 16 and net.filters[i + 2] == 16:       # (bf16 storage: the backward only)
                 got = topology.patch_plan(net._lap[i], int(net.K[j]) - 1, net._up[i])
                 if got is not None:
                     self._patch_keep.append(got)
