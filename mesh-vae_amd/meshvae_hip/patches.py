@@ -22,6 +22,8 @@ a level's graph into such patches, once, on the host:
 Nothing here touches values: A / D / U stay the fixtures' (SURVEY 8(c)); a plan changes which workgroup computes a
 row and in which order sums are formed (fp32 reassociation, inside the 1e-4 bars of nn/conv.py's contract).
 """
+import os
+
 import numpy as np
 
 ROW_STRIDE_16B = 5          # LDS row = 16 floats + 4 floats of padding (bank spread), in 16-byte units
@@ -216,6 +218,11 @@ class PatchPlan:
                 assert (nb >= 0).all(), "patch plan: a neighbour of an inner-ring vertex is outside the patch"
                 slots[li, :len(nb)] = nb
             slots = _conflict_aware_slots(slots, tot16, c[-2] if n_rings >= 1 else 0)
+            if os.environ.get("MESHVAE_PLAN_TIMING_ONLY") == "own_rows":
+                # TIMING ONLY, results invalid (tools/microbench_conv.py): every list entry names the vertex's OWN row, the
+                # pads stay -- no gather of a tile can conflict; what the kernels would cost with perfect lists
+                real = slots != tot16
+                slots = np.where(real, np.arange(tot16)[:, None], tot16)
             slots *= ROW_STRIDE_16B
             ell.append((slots[:, 0::2] | (slots[:, 1::2] << 16)).astype(np.uint32))
             pinfo.append(info)
