@@ -662,6 +662,32 @@ def test_piecewise_inference_calls_take_the_native_sequences():
     assert h.requires_grad
 
 
+def test_piecewise_inference_on_the_5k_model_runs_the_patch_kernels():
+    """... on the 5k template the native encode / decode sequences run the vertex-patch kernels (first layer:
+    k_patch_enc0, last decoder stage: k_patch_fwd) where the per-module path runs the slab kernels: the same numbers to
+    fp32 reassociation (and not bitwise -- the patch kernels really ran), also with the patch kernels switched off."""
+    from meshvae_hip import debug_switch
+    dev = torch.device("cuda:0")
+    B = 5
+    x = torch.randn(B, 4998, 3, generator=torch.Generator().manual_seed(10)).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    a, b = _ref_model("5k", dev).eval(), _ref_model("5k", dev).eval()
+    a.fused_step = False
+
+    def run(n_):
+        with torch.no_grad():
+            h = n_.encoder(x)
+            mu = n_.z_mean(torch.cat([y.float(), h], -1))
+            return h, n_.sample(y, mu)
+    ha, ra = run(a)
+    hb, rb = run(b)
+    with debug_switch("no_patch", 1):
+        hc, rc = run(b)
+    for u, v in ((ha, hb), (ra, rb), (ha, hc), (ra, rc)):
+        assert float((u - v).abs().max()) <= 2e-5 * float(u.abs().max()), float((u - v).abs().max())
+    assert not torch.equal(hb, hc), "no_patch changed nothing: the native encode did not run the first-layer patch kernel"
+
+
 def _bench_line(*extra):
     import json
     import subprocess
