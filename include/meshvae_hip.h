@@ -107,7 +107,14 @@ typedef struct mvh_patch_plan {
   const int32_t* pcol;
   const float* pval;
   const int32_t* pool_rowptr; /* rowptr of the pooling operator the rows above were taken from (identity check), or NULL */
-  int32_t max_pool_nnz, reserved; /* most pooling entries (pcol / pval) of one patch */
+  int32_t max_pool_nnz;       /* most pooling entries (pcol / pval) of one patch */
+  int32_t u_rows;             /* > 0: urec is there; rows of the COARSE level the un-pooling operator reads (its n_cols) */
+  /* Optional (plans built with the level's un-pooling operator U, nn/pool.py:17-20 forward, whose rows all have <= 3
+   * entries): urec[slot][6] = the three (coarse row id, fp32 weight bits) pairs of U's row for the local vertex, in the
+   * operator's own entry order, zero-weight pairs past the row's end.  The forward kernel of the level's 16 -> 16 layer
+   * can then take the COARSE tensor as its input and un-pool it while it loads (ConvIO::x_unpool inside the library:
+   * the step engine's last decoder stage), in the arithmetic of mvh_pool_fwd (one rounding per product and per sum). */
+  const uint32_t* urec;
 } mvh_patch_plan_t;
 
 /* val[e] == -d[row] * d[col] with d = rowlen^-1/2 (0 for empty rows): the normalised mesh
@@ -123,7 +130,7 @@ typedef struct mvh_patch_plan {
  * any other call (the Python binding does, meshvae_hip/__init__.py).  History: 100 = round 1; 300 = `storage`
  * inserted into mvh_vae_desc_t, skip_lo / skip_hi appended to mvh_adam_step / mvh_adam_step_counted (round 2,
  * shipped unversioned), version check introduced (round 3). */
-#define MVH_ABI_VERSION 320
+#define MVH_ABI_VERSION 321
 int mvh_version(void);
 const char* mvh_last_error(void);
 /* Device properties of the current HIP device (arch string e.g. "gfx950"). */

@@ -1055,7 +1055,8 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   // v_mfma_f32_16x16x4_f32 (cheb_patch.hip).  No fused pooling there: the decoder's LAST stage and module-level calls.
   if (!tx_saved && !bf && !pool && patch_eligible(lap, N, Cin, Cout, K) &&
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)W) & 15) == 0)
-    return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs);
+    return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs, io.x_unpool, io.x_store);
+  MVH_REQUIRE(!io.x_unpool, "cheb_conv_fwd: x_unpool on a layer that does not take the vertex-patch kernel");
   // the first layer (<= 4 -> 16) in front of its one-hot pooling, nobody reading the other rows: recurrence on the input
   // side in the patch image, pooled rows + their sign bytes + the weight gradient's T_k stack out of one launch (`out`
   // itself is never written: io.out, its storage type, does not matter)

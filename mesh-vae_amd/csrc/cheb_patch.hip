@@ -53,6 +53,7 @@ struct PatchDims {
   int cin;              // k_patch_enc0: input channels (<= 4)
   int out_bf16;         // k_patch_enc0: the pooled output rows are stored as bf16 (bf16.hpp); k_patch_bwd: dx / its pooled rows
   int x_bf16, dout_bf16;  // k_patch_bwd on bf16 STORAGE: x and the stored dout rows are bf16 tensors (fp32 arithmetic throughout)
+  int u_rows;           // k_patch_fwd, > 0: x is the COARSE tensor [B][u_rows][16], un-pooled through the plan's urec while loading
 };
 
 // float4 sums / fused multiply-adds as TWO packed instructions (v_pk_add_f32 / v_pk_fma_f32: two fp32 lanes per issue slot,
@@ -165,7 +166,7 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
             const float* __restrict__ p_bias, float* __restrict__ p_out, uint8_t* __restrict__ p_bits,
             const int32_t* __restrict__ p_poff,
             const int32_t* __restrict__ p_cnt, const uint32_t* __restrict__ p_pinfo, const uint32_t* __restrict__ p_ell,
-            PatchDims a) {
+            const uint32_t* __restrict__ p_urec, float* __restrict__ p_xstore, PatchDims a) {
   constexpr int NW = THREADS / 64;
   extern __shared__ __align__(16) unsigned char smem[];
   // blocks b and b + 8 share an XCD: the patches of one mesh (which share their halo rows) stay on one L2 (speed only)
@@ -218,6 +219,55 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
   };
   load_w(0);
   const float* xb = p_x + (long long)mesh * a.x_bs * 16;      // (strided x, ConvIO::x_map: row v of a mesh at x_map[v])
+  // Every load of the prologue in two rounds of independent loads, indices clamped and no branch around a load (written
+  // slot by slot behind their tests these were 2 x SLOTS dependent round trips: 12 k of the kernel's 60 k cycles): first
+  // the rows' plan words (and, un-pooling, their three taps), then what they point to.
+  uint32_t info[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) info[s] = p_pinfo[o + min(16 * (s * NW + w) + vi, rows16 - 1)];
+  float4 xv[SLOTS];
+  if (a.u_rows > 0) {
+    // the layer input is U x_coarse (nn/pool.py:17-20): three taps per row from the coarse tensor (5 MB, on chip), in
+    // the arithmetic of the pooling op -- every product and every sum rounded, the operator's entry order -- so the
+    // values are those a stored un-pooled tensor would hold.  Exclusive rows are written out once for the backward.
+    uint2 ur[SLOTS][3];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const uint2* up = reinterpret_cast<const uint2*>(p_urec + (size_t)(o + min(16 * (s * NW + w) + vi, rows16 - 1)) * 6);
+      ur[s][0] = up[0]; ur[s][1] = up[1]; ur[s][2] = up[2];
+    }
+    const float* xc = p_x + (long long)mesh * a.u_rows * 16 + 4 * q;
+    constexpr int H = (SLOTS + 1) / 2;      // the taps' rows in two halves (12 registers per slot in flight)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 n[H][3];
+#pragma unroll
+      for (int s = h * H; s < min((h + 1) * H, SLOTS); ++s)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[s - h * H][j] = *reinterpret_cast<const float4*>(xc + (long long)ur[s][j].x * 16);
+#pragma unroll
+      for (int s = h * H; s < min((h + 1) * H, SLOTS); ++s) {
+        const float4 n0 = n[s - h * H][0], n1 = n[s - h * H][1], n2 = n[s - h * H][2];
+        const float w0 = __uint_as_float(ur[s][0].y), w1 = __uint_as_float(ur[s][1].y), w2 = __uint_as_float(ur[s][2].y);
+        xv[s].x = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(w0, n0.x)), __fmul_rn(w1, n1.x)), __fmul_rn(w2, n2.x));
+        xv[s].y = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(w0, n0.y)), __fmul_rn(w1, n1.y)), __fmul_rn(w2, n2.y));
+        xv[s].z = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(w0, n0.z)), __fmul_rn(w1, n1.z)), __fmul_rn(w2, n2.z));
+        xv[s].w = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(w0, n0.w)), __fmul_rn(w1, n1.w)), __fmul_rn(w2, n2.w));
+        const int t = s * NW + w;
+        if (p_xstore && t < nt_all && (info[s] >> 24 & 15u) != 15u && ((info[s] >> 28) & 1u))
+          *reinterpret_cast<float4*>(p_xstore + ((long long)mesh * a.N + (info[s] & 0xffffu)) * 16 + 4 * q) = xv[s];
+      }
+    }
+  } else if (p_xmap) {
+    int xr[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) xr[s] = p_xmap[info[s] & 0xffffu];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) xv[s] = *reinterpret_cast<const float4*>(xb + (long long)xr[s] * 16 + 4 * q);
+  } else {
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) xv[s] = *reinterpret_cast<const float4*>(xb + (long long)(info[s] & 0xffffu) * 16 + 4 * q);
+  }
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) acc[s] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -225,16 +275,11 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
     const int t = s * NW + w;
     st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int v = 16 * t + vi;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < nt0) {
-      const uint32_t info = p_pinfo[o + v];
-      const float deg = (float)((info >> 16) & 255u);
-      const bool valid = (info >> 24 & 15u) != 15u;
-      const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
-      const int xr = p_xmap ? p_xmap[info & 0xffffu] : (int)(info & 0xffffu);
-      const float4 xv = *reinterpret_cast<const float4*>(xb + (long long)xr * 16 + 4 * q);
-      r = make_float4(xv.x * sc, xv.y * sc, xv.z * sc, xv.w * sc);
-    }
+    const float deg = (float)((info[s] >> 16) & 255u);
+    const bool valid = t < nt0 && (info[s] >> 24 & 15u) != 15u;
+    const float sc = valid ? (deg > 0.f ? __builtin_amdgcn_rsqf(deg) : 1.0f) : 0.f;
+    // (a clamped load of a slot nobody needs may hold anything: selected away, not multiplied by zero)
+    const float4 r = valid ? make_float4(xv[s].x * sc, xv[s].y * sc, xv[s].z * sc, xv[s].w * sc) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < nt_all) *reinterpret_cast<float4*>(u + (size_t)v * kRowF + 4 * q) = r;
     if (s < ASLOTS) mfma4(acc[s < ASLOTS ? s : 0], wa, r);     // (outside every run-time branch)
   }
@@ -942,6 +987,15 @@ bool patch_eligible(const mvh_csr_t* lap, int N, int Cin, int Cout, int K) {
   return cfg_fits(pl);
 }
 
+// the level's 16 -> 16 forward can take the coarse tensor and un-pool it in its loads: the plan was built with THIS
+// un-pooling operator (identity of its transpose's rowptr is not available here: the row counts and the operator's
+// shape are checked, the step engine builds both from the same Operator) and carries its rows
+bool patch_unpool_eligible(const mvh_csr_t* lap, const mvh_csr_t* up, int N, int Cin, int Cout, int K) {
+  if (dbg().no_patch_unpool == 1 || !patch_eligible(lap, N, Cin, Cout, K) || !up) return false;
+  const mvh_patch_plan_t* pl = lap->patch;
+  return pl->urec != nullptr && pl->u_rows > 0 && up->n_rows == N && up->n_cols == pl->u_rows && pl->n_pool_rows == pl->u_rows;
+}
+
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
   const mvh_patch_plan_t* pl = lap ? lap->patch : nullptr;
   if (!pl) return 0;
@@ -949,13 +1003,17 @@ size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
 }
 
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
-                     uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map, int x_bs) {
+                     uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map, int x_bs, bool x_unpool,
+                     float* x_store) {
   const mvh_patch_plan_t* pl = lap->patch;
+  MVH_REQUIRE(!x_unpool || (pl->urec && pl->u_rows > 0 && !x_map), "patch_fwd: the plan carries no un-pooling rows");
+  MVH_REQUIRE(((uintptr_t)x_store & 15) == 0, "patch_fwd: tensors must be 16-byte aligned");
   MVH_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "patch_fwd: tensors must be 16-byte aligned");
   MVH_REQUIRE(cfg_fits(pl), "patch_fwd: the plan does not fit the kernel's register arrays");
   PatchDims d{};
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = act;
   d.x_bs = x_map ? x_bs : N;
+  d.u_rows = x_unpool ? pl->u_rows : 0;
   using C = FwdCfg;
   // slots that are core tiles for every wave of every patch
   const bool su_ok = (pl->min_core / 16) / (C::THREADS / 64) >= C::SU;
@@ -965,7 +1023,7 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, x_map, W, bias, out, bits, pl->poff, pl->cnt,
-                     pl->pinfo, pl->ell, d);
+                     pl->pinfo, pl->ell, pl->urec, x_unpool ? x_store : nullptr, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

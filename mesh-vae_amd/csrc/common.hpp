@@ -133,6 +133,7 @@ struct DebugCfg {
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
   int no_patch_bf16 = 0;   // 1: bf16 storage keeps the matrix-pipe slab kernels (cheb_l0h.hip) for the 5k level's backward
+  int no_patch_unpool = 0; // 1: the last decoder stage reads a stored un-pooled input (the stage before writes it) instead of un-pooling in its loads
   int no_enc0_patch = 0;   // 1: the first layer's forward stays on the slab kernel and the backward builds its stack (k_cheb_tstack)
   int patch_flush_first = 1;   // the step forks the weight-gradient items queued so far (the final layer's) BEFORE a patch backward
                                // launch, so that they run beside it (MEASURED: 458 against 485 us per step; 0: behind it)
@@ -275,6 +276,12 @@ struct ConvIO {
   // cheb_tstack.hip, in stack_out, and says so in *stack_done (left untouched on every other path)
   float* stack_out = nullptr;
   bool* stack_done = nullptr;
+  // forward of a 16 -> 16 layer on the vertex-patch kernel whose plan carries the level's un-pooling rows (urec): `x` is the
+  // COARSE tensor [B][plan.u_rows][16] and the kernel un-pools it while it loads (the previous stage then stores no
+  // un-pooled rows: 20 MB less written and read at the 5k level); x_store != NULL: the un-pooled rows [B][N][16] are
+  // written there once (the backward's dW operand).  Patch kernel only (patch_unpool_eligible); every other path refuses.
+  bool x_unpool = false;
+  float* x_store = nullptr;
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?
@@ -311,7 +318,8 @@ int launch_patch_enc0(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* dow
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K);
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
                      uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map = nullptr /* ConvIO::x_map */,
-                     int x_bs = 0);
+                     int x_bs = 0, bool x_unpool = false /* ConvIO::x_unpool */, float* x_store = nullptr);
+bool patch_unpool_eligible(const mvh_csr_t* lap, const mvh_csr_t* up, int N, int Cin, int Cout, int K);
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,
                      float* part, size_t part_bytes, DwReduceEntry* defer, float* dW, float* db, int B, int N, int K,

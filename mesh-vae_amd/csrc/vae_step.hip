@@ -451,6 +451,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   // stage's conv kernel (pooled rows gathered from LDS in its epilogue, no pool launch)
   TRY(check_csr(&d->up[n - 1], "up"));
   TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
+  bool unpool_in_next = false;      // this stage's input is still coarse: its vertex-patch kernel un-pools while it loads
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
@@ -458,9 +459,22 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     ConvIO io;
     io.x = io.out = io.pooled = bf;
     if (i == n - 1 && p.pk_h_f != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_f));
-    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], F(p.decU[i]), P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
+    const float* xin = F(p.decU[i]);
+    if (unpool_in_next) {            // (decided by the stage before, which stored no un-pooled rows)
+      xin = F(p.decC[i - 1]);
+      io.x_unpool = true;
+      io.x_store = ((phases & kPhLoss) && dbg().no_patch_unpool != 2) ? F(p.decU[i]) : nullptr;   // the backward's dW operand; a decode-only call has no use for it (no_patch_unpool = 2: TIMING ONLY, never stored)
+    }
+    // the NEXT stage on a vertex-patch plan that carries U's rows (fp32 storage; the 5k level): no un-pooled tensor is
+    // written here (20 MB as 16-byte pieces of 64-byte rows from this kernel's 4-channel slabs), the next kernel gathers
+    // three coarse rows per vertex from this stage's 5 MB output instead of reading it
+    unpool_in_next = more && !bf && !p.txDec.empty() && TX(p.txDec[i + 1]) == nullptr &&
+                     patch_unpool_eligible(&d->lap[lvl - 1], &d->up[lvl - 1], p.Nn[lvl - 1], p.f[n - i], p.f[n - i - 1], d->K[i + 1]) &&
+                     ((((uintptr_t)F(p.decC[i])) | ((uintptr_t)F(p.decU[i + 1]))) & 15) == 0;
+    const bool pool_here = more && !unpool_in_next;
+    TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[lvl], xin, P[ix.decW(i)], P[ix.decB(i)], F(p.decC[i]),
                            bf ? nullptr : TX(p.txDec[i]), B, p.Nn[lvl], cin, cout, d->K[i], MVH_ACT_RELU, sm, p.scratch_bytes,
-                           F(p.pk_dec_f[i]), more ? &d->up[lvl - 1] : nullptr, more ? F(p.decU[i + 1]) : nullptr,
+                           F(p.pk_dec_f[i]), pool_here ? &d->up[lvl - 1] : nullptr, pool_here ? F(p.decU[i + 1]) : nullptr,
                            BITS(p.decBits[i]), nullptr, io));
     cur = F(p.decC[i]);
   }

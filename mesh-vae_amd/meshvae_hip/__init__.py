@@ -54,7 +54,7 @@ class PatchPlanStruct(ctypes.Structure):
                 ("poff", ctypes.c_void_p), ("cnt", ctypes.c_void_p), ("pinfo", ctypes.c_void_p), ("ell", ctypes.c_void_p),
                 ("prow_off", ctypes.c_void_p), ("prow_gid", ctypes.c_void_p), ("prow_ptr", ctypes.c_void_p),
                 ("pcol", ctypes.c_void_p), ("pval", ctypes.c_void_p), ("pool_rowptr", ctypes.c_void_p),
-                ("max_pool_nnz", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("max_pool_nnz", ctypes.c_int32), ("u_rows", ctypes.c_int32), ("urec", ctypes.c_void_p)]
 
 
 VAE_MAX_LAYERS = 8
@@ -74,7 +74,7 @@ class VaeDesc(ctypes.Structure):
 
 CSR_NORMALIZED_LAPLACIAN, CSR_SYMMETRIC, CSR_SELECTION, CSR_ELL_OVERFLOW = 1, 2, 4, 8
 STORAGE_F32, STORAGE_BF16 = 0, 1
-ABI_VERSION = 320   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
+ABI_VERSION = 321   # MVH_ABI_VERSION of include/meshvae_hip.h this binding was written against
 _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_size_t
 _CSR = ctypes.POINTER(CsrStruct)
 

@@ -264,6 +264,27 @@ class PatchPlan:
             tot += sum(int(c[1 + min(self.n_rings, K - 1 - k)]) for k in range(1, K))
         return tot / max(1, self.n * (K - 1))
 
+    def attach_unpool(self, rowptr, col, val, n_coarse):
+        """U itself (forward CSR: rows = this level's vertices, columns = the coarse level's), for the forward kernel's
+        un-pooling loads: urec[slot] = three (coarse row, weight bits) pairs in U's entry order.  Only when every row has at
+        most three entries (barycentric up-sampling); otherwise the plan carries none and the caller un-pools first."""
+        rowptr, col, val = np.asarray(rowptr, dtype=np.int64), np.asarray(col, dtype=np.int64), np.asarray(val, dtype=np.float32)
+        self.urec, self.u_rows = None, 0
+        if len(rowptr) != self.n + 1 or (rowptr[1:] - rowptr[:-1]).max() > 3 or n_coarse <= 0:
+            return False
+        gid = (self.pinfo & 0xffff).astype(np.int64)
+        live = ((self.pinfo >> 24) & 15) != 15
+        rec = np.zeros((len(self.pinfo), 6), dtype=np.uint32)
+        for j in range(3):
+            e = rowptr[gid] + j
+            ok = live & (e < rowptr[gid + 1])
+            ee = np.where(ok, e, 0)
+            rec[:, 2 * j] = np.where(ok, col[ee], 0).astype(np.uint32)
+            rec[:, 2 * j + 1] = np.where(ok, val[ee], np.float32(0)).astype(np.float32).view(np.uint32)
+        self.urec, self.u_rows = rec, int(n_coarse)
+        self._dev.clear()
+        return True
+
     def device(self, dev, pool_rowptr=None):
         """-> (PatchPlanStruct, tensors kept alive) on torch device `dev`; pool_rowptr: the device rowptr tensor of the
         pooling operator the plan was built from (the kernels' identity check)"""
@@ -277,12 +298,17 @@ class PatchPlan:
             for k in ("prow_gid", "prow_ptr", "pcol", "pval"):     # (never empty pointers: one dummy element)
                 if t[k].numel() == 0:
                     t[k] = torch.zeros(1, dtype=t[k].dtype, device=dev)
+            urec = getattr(self, "urec", None)
+            if urec is not None:
+                t["urec"] = torch.from_numpy(np.ascontiguousarray(urec).view(np.int32)).to(dev)
             s = PatchPlanStruct(self.n_patches, self.n_rings, self.n, self.max_rows, int(self.cnt[:, 1].max()),
                                 int(self.cnt[:, 0].max()), self.n_pool_rows, int(self.cnt[:, 1].min()),
                                 t["poff"].data_ptr(), t["cnt"].data_ptr(), t["pinfo"].data_ptr(), t["ell"].data_ptr(),
                                 t["prow_off"].data_ptr(), t["prow_gid"].data_ptr(), t["prow_ptr"].data_ptr(),
                                 t["pcol"].data_ptr(), t["pval"].data_ptr(),
-                                None if pool_rowptr is None else pool_rowptr.data_ptr(), self.max_pool_nnz, 0)
+                                None if pool_rowptr is None else pool_rowptr.data_ptr(), self.max_pool_nnz,
+                                getattr(self, "u_rows", 0) if urec is not None else 0,
+                                t["urec"].data_ptr() if urec is not None else None)
             t["pool_rowptr"] = pool_rowptr
             self._dev[key] = (s, t)
         return self._dev[key]

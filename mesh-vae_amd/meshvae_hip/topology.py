@@ -249,6 +249,9 @@ def patch_plan(lap_op, n_rings, up_op=None, down_op=None):
             pool_t = (t.rowptr.cpu().numpy().astype(np.int64), t.col.cpu().numpy().astype(np.int64), t.val.cpu().numpy())
             pool_rowptr = t.rowptr
         plan = patches.build_plan(csr.n_rows, rows, cols, int(n_rings), pool_t)
+        if plan is not None and up_op is not None and up_op.fwd.n_rows == csr.n_rows and getattr(plan, "urec", None) is None:
+            u = up_op.fwd                                     # U: rows = this level, columns = the coarse level
+            plan.attach_unpool(u.rowptr.cpu().numpy(), u.col.cpu().numpy(), u.val.cpu().numpy(), u.n_cols)
         cache[key] = None if plan is None else plan.device(csr.rowptr.device, pool_rowptr) + (plan, up_op if up_op is not None else down_op)
     return cache[key]
 

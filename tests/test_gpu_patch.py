@@ -197,3 +197,15 @@ def test_first_layer_patch_kernel_in_the_step(storage):
     for k in b[3]:
         rel = float((a[3][k] - b[3][k]).norm() / b[3][k].norm().clamp_min(1e-20))
         assert rel < (1e-4 if storage == "f32" else 5e-2), (k, rel)
+
+
+def test_unpooling_inside_the_patch_forward_is_bitwise_the_stored_form():
+    """The last decoder stage's forward takes the COARSE tensor and un-pools it while it loads (plan rows `urec`, three taps
+    per vertex in the pooling op's arithmetic); the stage before it then stores no un-pooled rows.  Against the stored form
+    (debug switch no_patch_unpool: the previous stage's kernel writes U x from its epilogue) the whole step is the same
+    bit for bit -- outputs and every gradient -- and the un-pooled tensor the backward reads is the one the forward wrote."""
+    a = _step_5k({})
+    b = _step_5k({"no_patch_unpool": 1})
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in b[3]:
+        assert torch.equal(a[3][k], b[3][k]), k

@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, s), f"{s} declared in include/meshvae_hip.h but not exported"
         assert s in meshvae_hip.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(meshvae_hip.SIGNATURES) == syms
-    assert lib.mvh_version() == meshvae_hip.ABI_VERSION == 320
+    assert lib.mvh_version() == meshvae_hip.ABI_VERSION == 321
 
 
 def test_host_library_exports_every_header_symbol():
