@@ -1055,7 +1055,13 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   // v_mfma_f32_16x16x4_f32 (cheb_patch.hip).  No fused pooling there: the decoder's LAST stage and module-level calls.
   if (!tx_saved && !bf && !pool && patch_eligible(lap, N, Cin, Cout, K) &&
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)W) & 15) == 0)
-    return launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs, io.x_unpool, io.x_store);
+  {
+    const bool map = io.map_out && io.map_w && !dbg().no_patch_map;
+    if (int rc = launch_patch_fwd(st, lap, x, W, bias, out, bits_out, B, N, K, act, io.x_map, io.x_bs, io.x_unpool, io.x_store,
+                                  map ? io.map_w : nullptr, map ? io.map_out : nullptr, io.map_c, io.map_n0)) return rc;
+    if (map && io.map_done) *io.map_done = true;
+    return MVH_OK;
+  }
   MVH_REQUIRE(!io.x_unpool, "cheb_conv_fwd: x_unpool on a layer that does not take the vertex-patch kernel");
   // the first layer (<= 4 -> 16) in front of its one-hot pooling, nobody reading the other rows: recurrence on the input
   // side in the patch image, pooled rows + their sign bytes + the weight gradient's T_k stack out of one launch (`out`

@@ -54,6 +54,7 @@ struct PatchDims {
   int out_bf16;         // k_patch_enc0: the pooled output rows are stored as bf16 (bf16.hpp); k_patch_bwd: dx / its pooled rows
   int x_bf16, dout_bf16;  // k_patch_bwd on bf16 STORAGE: x and the stored dout rows are bf16 tensors (fp32 arithmetic throughout)
   int u_rows;           // k_patch_fwd, > 0: x is the COARSE tensor [B][u_rows][16], un-pooled through the plan's urec while loading
+  int map_c, map_n0;    // k_patch_fwd, map_c > 0: rows >= map_n0 of out3 [B][N][map_c] (map_c <= 4) = this layer's output x w3 [16][map_c]
 };
 
 // float4 sums / fused multiply-adds as TWO packed instructions (v_pk_add_f32 / v_pk_fma_f32: two fp32 lanes per issue slot,
@@ -166,7 +167,8 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
             const float* __restrict__ p_bias, float* __restrict__ p_out, uint8_t* __restrict__ p_bits,
             const int32_t* __restrict__ p_poff,
             const int32_t* __restrict__ p_cnt, const uint32_t* __restrict__ p_pinfo, const uint32_t* __restrict__ p_ell,
-            const uint32_t* __restrict__ p_urec, float* __restrict__ p_xstore, PatchDims a) {
+            const uint32_t* __restrict__ p_urec, float* __restrict__ p_xstore, const float* __restrict__ p_w3,
+            float* __restrict__ p_out3, PatchDims a) {
   constexpr int NW = THREADS / 64;
   extern __shared__ __align__(16) unsigned char smem[];
   // blocks b and b + 8 share an XCD: the patches of one mesh (which share their halo rows) stay on one L2 (speed only)
@@ -345,6 +347,16 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
   // ---- epilogue: D^1/2, bias, activation, one 16-byte store per lane (+ one sign byte)
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p_bias) b4 = *reinterpret_cast<const float4*>(p_bias + 4 * q);
+  // optional per-vertex map behind the layer (the final conv of the VAE, cheb_VAE.py:288, off its 20-vertex block:
+  // recon[v][o] = sum_c out[v][c] W_eff[c][o]): lane (vertex, quad q) collects the vertex's other three quads from its
+  // sister lanes and runs output o = q's 16-term fma chain in k_cheb_contract's order, so the values are bitwise those of
+  // the separate launch (or of the loss launch's fused form) -- which then never reads this layer's 20 MB output
+  float wq[16];
+  const int mo = min(q, max(a.map_c - 1, 0));
+  if (a.map_c > 0) {
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) wq[cc] = p_w3[cc * a.map_c + mo];
+  }
 #pragma unroll
   for (int s = 0; s < ASLOTS; ++s) {
     const int t = s * NW + w;
@@ -360,6 +372,21 @@ k_patch_fwd(const float* __restrict__ p_x, const int32_t* __restrict__ p_xmap, c
       *reinterpret_cast<float4*>(p_out + row * 16 + 4 * q) = make_float4(r0, r1, r2, r3);
       if (p_bits)
         p_bits[row * 4 + q] = (uint8_t)((r0 > 0.f ? 1 : 0) | (r1 > 0.f ? 2 : 0) | (r2 > 0.f ? 4 : 0) | (r3 > 0.f ? 8 : 0));
+      if (a.map_c > 0) {      // (uniform; the four lanes of a vertex share the test around this block)
+        float xa16[16];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          xa16[4 * qq + 0] = __shfl(r0, vi + 16 * qq, 64);
+          xa16[4 * qq + 1] = __shfl(r1, vi + 16 * qq, 64);
+          xa16[4 * qq + 2] = __shfl(r2, vi + 16 * qq, 64);
+          xa16[4 * qq + 3] = __shfl(r3, vi + 16 * qq, 64);
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) m = fmaf(xa16[cc], wq[cc], m);
+        const int gid = (int)(info & 0xffffu);
+        if (q < a.map_c && gid >= a.map_n0) p_out3[row * a.map_c + q] = m;
+      }
     }
   }
   MVH_STAMPX(27);
@@ -1004,7 +1031,7 @@ size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K) {
 
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
                      uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map, int x_bs, bool x_unpool,
-                     float* x_store) {
+                     float* x_store, const float* map_w, float* map_out, int map_c, int map_n0) {
   const mvh_patch_plan_t* pl = lap->patch;
   MVH_REQUIRE(!x_unpool || (pl->urec && pl->u_rows > 0 && !x_map), "patch_fwd: the plan carries no un-pooling rows");
   MVH_REQUIRE(((uintptr_t)x_store & 15) == 0, "patch_fwd: tensors must be 16-byte aligned");
@@ -1014,6 +1041,8 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   d.B = B; d.N = N; d.K = K; d.P = pl->n_patches; d.R = pl->n_rings; d.act = act;
   d.x_bs = x_map ? x_bs : N;
   d.u_rows = x_unpool ? pl->u_rows : 0;
+  MVH_REQUIRE(!map_out || (map_w && map_c >= 1 && map_c <= 4 && map_n0 >= 0), "patch_fwd: bad per-vertex map");
+  d.map_c = map_out ? map_c : 0; d.map_n0 = map_n0;
   using C = FwdCfg;
   // slots that are core tiles for every wave of every patch
   const bool su_ok = (pl->min_core / 16) / (C::THREADS / 64) >= C::SU;
@@ -1023,7 +1052,7 @@ int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const
   if (int rc = attr[su_ok].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   const int grid = ((d.B + 7) / 8) * 8 * d.P;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), lds, st, x, x_map, W, bias, out, bits, pl->poff, pl->cnt,
-                     pl->pinfo, pl->ell, pl->urec, x_unpool ? x_store : nullptr, d);
+                     pl->pinfo, pl->ell, pl->urec, x_unpool ? x_store : nullptr, map_w, map_out, d);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

@@ -133,6 +133,7 @@ struct DebugCfg {
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
   int no_patch_bf16 = 0;   // 1: bf16 storage keeps the matrix-pipe slab kernels (cheb_l0h.hip) for the 5k level's backward
+  int no_patch_map = 0;    // 1: the final layer's per-vertex map stays in the loss launch / its own launch (not in the last decoder stage's epilogue)
   int no_patch_unpool = 0; // 1: the last decoder stage reads a stored un-pooled input (the stage before writes it) instead of un-pooling in its loads
   int no_enc0_patch = 0;   // 1: the first layer's forward stays on the slab kernel and the backward builds its stack (k_cheb_tstack)
   int patch_flush_first = 1;   // the step forks the weight-gradient items queued so far (the final layer's) BEFORE a patch backward
@@ -282,6 +283,13 @@ struct ConvIO {
   // written there once (the backward's dW operand).  Patch kernel only (patch_unpool_eligible); every other path refuses.
   bool x_unpool = false;
   float* x_store = nullptr;
+  // ... and a per-vertex map BEHIND the layer, out of the same kernel's epilogue: rows >= map_n0 of map_out [B][N][map_c]
+  // = out x map_w [Cout = 16][map_c] (map_c <= 4), in k_cheb_contract's fma order.  The VAE's final conv off its connected
+  // block (cheb_VAE.py:288): neither that layer's map launch nor the loss launch then reads this layer's output.
+  const float* map_w = nullptr;
+  float* map_out = nullptr;
+  int map_c = 0, map_n0 = 0;
+  bool* map_done = nullptr;     // set when the kernel that honours map_* ran (every other path leaves it alone)
   bool any() const { return x || out || pooled || dout || dx || dx_pooled; }
 };
 // does this layer take the split path of cheb_conv.hip (mostly-isolated Laplacian: per-vertex map + connected block)?
@@ -318,7 +326,8 @@ int launch_patch_enc0(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* dow
 size_t patch_part_bytes(const mvh_csr_t* lap, int B, int K);
 int launch_patch_fwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* bias, float* out,
                      uint8_t* bits, int B, int N, int K, int act, const int32_t* x_map = nullptr /* ConvIO::x_map */,
-                     int x_bs = 0, bool x_unpool = false /* ConvIO::x_unpool */, float* x_store = nullptr);
+                     int x_bs = 0, bool x_unpool = false /* ConvIO::x_unpool */, float* x_store = nullptr,
+                     const float* map_w = nullptr /* ConvIO::map_* */, float* map_out = nullptr, int map_c = 0, int map_n0 = 0);
 bool patch_unpool_eligible(const mvh_csr_t* lap, const mvh_csr_t* up, int N, int Cin, int Cout, int K);
 int launch_patch_bwd(hipStream_t st, const mvh_csr_t* lap, const float* x, const float* W, const float* dout,
                      const uint8_t* mbits, const float* g3, const float* w3, int src3_n, float* dx, bool pooled,

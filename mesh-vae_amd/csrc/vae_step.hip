@@ -452,6 +452,8 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   TRY(check_csr(&d->up[n - 1], "up"));
   TRY(launch_spmm((hipStream_t)stream, &d->up[n - 1], F(p.d2), F(p.decU[0]), nullptr, nullptr, 1.f, 0.f, B, p.f[n + 1], true, bf));
   bool unpool_in_next = false;      // this stage's input is still coarse: its vertex-patch kernel un-pools while it loads
+  bool map_done = false;            // the last stage's kernel wrote the final layer's per-vertex map (rows off its connected block)
+  const bool split_final = conv_split_eligible(&d->lap[n], p.Nn[0], p.f[1], p.f[0], d->K[n]);
   for (int i = 0; i < n; ++i) {
     const int lvl = n - i - 1, cin = p.f[n + 1 - i], cout = p.f[n - i];
     const bool more = i + 1 < n;
@@ -459,6 +461,12 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     ConvIO io;
     io.x = io.out = io.pooled = bf;
     if (i == n - 1 && p.pk_h_f != kNoBits) io.wh = reinterpret_cast<const uint32_t*>(F(p.pk_h_f));
+    if (i == n - 1 && !bf && split_final && p.f[1] == 16 && p.f[0] <= 4 && recon) {
+      // the final conv (cheb_VAE.py:288) off its connected block is the per-vertex map x16 W_eff: out of this stage's
+      // epilogue when it runs the vertex-patch kernel (W_eff comes from the step's pack launch)
+      io.map_w = F(p.weff_final); io.map_out = recon; io.map_c = p.f[0]; io.map_n0 = d->lap[n].n_active;
+      io.map_done = &map_done;
+    }
     const float* xin = F(p.decU[i]);
     if (unpool_in_next) {            // (decided by the stage before, which stored no un-pooled rows)
       xin = F(p.decC[i - 1]);
@@ -487,7 +495,7 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
     MVH_RANGE("fwd final conv N=%d %d->%d", p.Nn[0], p.f[1], p.f[0]);
     ConvIO io;
     io.x = bf;   // (the reconstruction itself is an fp32 tensor)
-    io.out_lazy = fuse_final;
+    io.out_lazy = fuse_final || map_done;      // (map_done: the rows off the connected block are already in `recon`)
     TRY(cheb_conv_fwd_impl((hipStream_t)stream, &d->lap[n], cur, P[ix.decW(n)], nullptr, recon, nullptr, B, p.Nn[0], p.f[1],
                            p.f[0], d->K[n], MVH_ACT_NONE, sm, p.scratch_bytes, F(p.pk_dec_f[n]), nullptr, nullptr, nullptr,
                            F(p.weff_final), io));
@@ -498,7 +506,8 @@ static int vae_forward_impl(mvh_stream_t stream, const mvh_vae_desc_t* d, const 
   MVH_RANGE("fwd loss");
   return loss_fwd_impl((hipStream_t)stream, recon, x_gt, gt_f64, mu, logvar, y, y_hat, log_sigma, loss, rec, kld,
                        correct, B, p.Nn[0] * p.F0, p.C, p.Z, sm, p.scratch_bytes, F(p.g_recon), F(p.d_mu), F(p.d_lv),
-                       F(p.d_yhat), fuse_final ? cur : nullptr, F(p.weff_final), recon, p.f[1], p.F0, d->lap[n].n_active);
+                       F(p.d_yhat), (fuse_final && !map_done) ? cur : nullptr, F(p.weff_final), recon, p.f[1], p.F0,
+                       d->lap[n].n_active);
 }
 
 extern "C" int mvh_vae_forward(mvh_stream_t stream, const mvh_vae_desc_t* d, const float* const* P, const float* x,

@@ -209,3 +209,15 @@ def test_unpooling_inside_the_patch_forward_is_bitwise_the_stored_form():
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for k in b[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_final_layer_map_out_of_the_patch_forward_is_bitwise_the_loss_launch_form():
+    """The final conv off its 20-vertex block is the per-vertex map x16 W_eff (cheb_VAE.py:288).  The last decoder stage's
+    patch kernel writes it from its epilogue (the vertex's four quads collected in one lane, k_cheb_contract's 16-term fma
+    chain), so neither a map launch nor the loss launch reads that stage's 20 MB output again.  Against the form that
+    computes it inside the loss launch (debug switch no_patch_map) the step is the same bit for bit."""
+    a = _step_5k({})
+    b = _step_5k({"no_patch_map": 1})
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in b[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
