@@ -124,3 +124,37 @@ def test_graphs_without_a_compact_cut_get_no_plan():
     star_r, star_c = np.zeros(12, dtype=np.int64), np.arange(1, 13)
     ring_r, ring_c = np.arange(2500), (np.arange(2500) + 1) % 2500
     assert pt.build_plan(2500, np.concatenate([star_r, ring_r]), np.concatenate([star_c, ring_c]), 5) is None
+
+
+def test_unpool_records_reproduce_the_operator():
+    """PatchPlan.attach_unpool: urec[slot] = the three (coarse row, weight) taps of U's row for the slot's vertex, in the
+    operator's entry order -- every real slot reproduces (U x)[vertex] with the pooling op's arithmetic (fp32 products and
+    sums, one rounding each), pad slots carry zero weights; an operator with a longer row gets no records."""
+    patches = _patches()
+    npz = load_golden("topology_5k.npz")
+    n = int(npz["num_nodes"][0])
+    plan = patches.build_plan(n, npz["A0_row"].astype(np.int64), npz["A0_col"].astype(np.int64), 5, _pool_t(npz))
+    ur, uc, uv = npz["U0_row"].astype(np.int64), npz["U0_col"].astype(np.int64), npz["U0_val"].astype(np.float32)
+    order = np.argsort(ur, kind="stable")                # CSR over rows, the COO entry order kept inside a row (topology.Operator)
+    ur, uc, uv = ur[order], uc[order], uv[order]
+    n1 = int(npz["U0_shape"][1])
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, ur + 1, 1)
+    rp = np.cumsum(rp)
+    assert plan.attach_unpool(rp, uc, uv, n1) and plan.u_rows == n1 and plan.urec.shape == (len(plan.pinfo), 6)
+    x = np.random.default_rng(0).standard_normal((n1, 4)).astype(np.float32)
+    want = np.zeros((n, 4), np.float32)
+    for e in range(len(ur)):                             # the pooling op: products and sums rounded one by one, entry order
+        want[ur[e]] = (want[ur[e]] + (uv[e] * x[uc[e]]).astype(np.float32)).astype(np.float32)
+    gid = (plan.pinfo & 0xffff).astype(np.int64)
+    live = ((plan.pinfo >> 24) & 15) != 15
+    got = np.zeros((len(plan.pinfo), 4), np.float32)
+    for j in range(3):
+        w = plan.urec[:, 2 * j + 1].view(np.float32)
+        got = (got + (w[:, None] * x[plan.urec[:, 2 * j].astype(np.int64)]).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(got[live], want[gid[live]])
+    assert not plan.urec[~live].any()
+    # four entries in one row: no records
+    rp2 = rp.copy()
+    rp2[1:] += 1
+    assert not plan.attach_unpool(rp2, np.concatenate([uc[:1], uc]), np.concatenate([uv[:1], uv]), n1) and plan.urec is None
