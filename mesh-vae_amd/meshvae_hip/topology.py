@@ -249,6 +249,11 @@ def patch_plan(lap_op, n_rings, up_op=None, down_op=None):
             pool_t = (t.rowptr.cpu().numpy().astype(np.int64), t.col.cpu().numpy().astype(np.int64), t.val.cpu().numpy())
             pool_rowptr = t.rowptr
         plan = patches.build_plan(csr.n_rows, rows, cols, int(n_rings), pool_t)
+        # a cut into small patches is all halo: below ~900 exclusive vertices per patch (K = 10 on a 5k level: 8 patches of
+        # 625 whose 9 rings make 1632 rows each, 1.5 x the row-orders and two rounds of workgroups at B = 64) the slab
+        # kernels are faster -- no plan then
+        if plan is not None and csr.n_rows / plan.n_patches < 900:
+            plan = None
         if plan is not None and up_op is not None and up_op.fwd.n_rows == csr.n_rows and getattr(plan, "urec", None) is None:
             u = up_op.fwd                                     # U: rows = this level, columns = the coarse level
             plan.attach_unpool(u.rowptr.cpu().numpy(), u.col.cpu().numpy(), u.val.cpu().numpy(), u.n_cols)
