@@ -23,11 +23,19 @@ typedef float f4nt_c __attribute__((ext_vector_type(4)));
 static bool dw_is_mfma(long long rows, int Cout);
 
 // ------------------------------------------------------------------ forward contraction
+// optional extras of the contraction's epilogue (Cout % 4 == 0 forms): sign bytes, and for 16 output channels a per-vertex map
+struct ContractExtra {
+  uint8_t* bits = nullptr;
+  const float* map_w = nullptr;
+  float* map_out = nullptr;
+  int map_c = 0, map_n0 = 0, N = 1;
+};
+
 template <int COUT_T, bool FULL, bool VIN>
 __global__ void __launch_bounds__(256)
 k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const float* __restrict__ W,
                 const float* __restrict__ bias, float* __restrict__ out, long long rows, int Cin,
-                int Cout, int K, int act, int x_bf16, int pmN) {
+                int Cout, int K, int act, int x_bf16, int pmN, ContractExtra ex) {
   // x_bf16: x is stored as bf16 (K == 1 only: the W_eff pass of the split path; the launcher checks)
   // pmN != 0: the stack planes tx are pair-major [B][8][|pmN|][2] (cheb_big.hip; 16 -> 16 only, the launcher checks);
   // pmN < 0: T_0 is plane 0 of that stack as well (x is not read) and T_k plane k -- the backward's T_k(dpre) stack
@@ -124,6 +132,25 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
 #pragma unroll
     for (int co = 0; co < COUT_T; co += 4)
       *reinterpret_cast<float4*>(o + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    if (ex.bits) {   // the ReLU sign bytes the backward masks with (one per 4 channels), instead of a k_relu_bits pass over `out`
+#pragma unroll
+      for (int co = 0; co < COUT_T; co += 4)
+        ex.bits[r * (COUT_T / 4) + co / 4] = (uint8_t)((acc[co] > 0.f ? 1 : 0) | (acc[co + 1] > 0.f ? 2 : 0) |
+                                                         (acc[co + 2] > 0.f ? 4 : 0) | (acc[co + 3] > 0.f ? 8 : 0));
+    }
+    if constexpr (COUT_T == 16) {
+      if (ex.map_out) {   // per-vertex map behind the layer (ConvIO::map_*): rows >= map_n0 of a mesh, the fma chain of this kernel's K = 1 form
+        const int v = (int)(r % ex.N);
+        if (v >= ex.map_n0) {
+          for (int oo = 0; oo < ex.map_c; ++oo) {
+            float m = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) m = fmaf(acc[cc], ex.map_w[cc * ex.map_c + oo], m);
+            ex.map_out[r * ex.map_c + oo] = m;
+          }
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int co = 0; co < COUT_T; ++co)
@@ -133,7 +160,11 @@ k_cheb_contract(const float* __restrict__ x, const float* __restrict__ tx, const
 
 static int launch_contract(hipStream_t st, const float* x, const float* tx, const float* W,
                            const float* bias, float* out, long long rows, int Cin, int Cout, int K,
-                           int act, bool x_bf16 = false, int pmN = 0) {
+                           int act, bool x_bf16 = false, int pmN = 0, ContractExtra ex = ContractExtra()) {
+  if (ex.bits && (Cout % 4 != 0 || !(Cout == 8 || Cout == 16 || Cout == 32) || act != MVH_ACT_RELU))
+    return fail(MVH_ERR_INVALID, "cheb_conv: sign bytes out of the contraction need ReLU and 8 / 16 / 32 output channels");
+  if (ex.map_out && (Cout != 16 || !ex.map_w || ex.map_c < 1 || ex.map_c > 4 || ex.N < 1))
+    return fail(MVH_ERR_INVALID, "cheb_conv: the per-vertex map rides on the 16-channel contraction only");
   const bool vin = (Cin % 4 == 0) && (((uintptr_t)x | (uintptr_t)tx) % 16 == 0);
   // pmN != 0: pair-major stack planes -- only the 16 -> 16 fast path of the kernel reads them (< 0: T_0 in the stack)
   if (pmN && !(vin && Cin == 16 && Cout == 16)) return fail(MVH_ERR_INVALID, "cheb_conv: pair-major stack outside the 16 -> 16 contraction");
@@ -143,7 +174,7 @@ static int launch_contract(hipStream_t st, const float* x, const float* tx, cons
   const int grid = cdiv(rows, 256);
 #define MVH_C(CT, FULL, VIN)                                                                    \
   hipLaunchKernelGGL((k_cheb_contract<CT, FULL, VIN>), dim3(grid), dim3(256), 0, st, x, tx, W,  \
-                     bias, out, rows, Cin, Cout, K, act, xb, pmN)
+                     bias, out, rows, Cin, Cout, K, act, xb, pmN, ex)
 #define MVH_CV(CT, FULL) \
   do { if (vin) MVH_C(CT, FULL, true); else MVH_C(CT, FULL, false); } while (0)
   if (Cout == 3) MVH_CV(3, true);
@@ -1113,10 +1144,16 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   }
   const int pmN = tx_pair_major(lap, x, tx, B, N, Cin, Cout, K);
   if (int rc = tx_forward(st, lap, x, tx, plane, B, Cin, K, pmN)) return rc;
-  if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act, false, pmN)) return rc;
+  ContractExtra ex;
+  const bool bits_here = bits_out && act == MVH_ACT_RELU && (Cout == 8 || Cout == 16 || Cout == 32) && !dbg().no_contract_extras;
+  if (bits_here) ex.bits = bits_out;
+  const bool map_here = io.map_out && io.map_w && Cout == 16 && !dbg().no_patch_map && !dbg().no_contract_extras;
+  if (map_here) { ex.map_w = io.map_w; ex.map_out = io.map_out; ex.map_c = io.map_c; ex.map_n0 = io.map_n0; ex.N = N; }
+  if (int rc = launch_contract(st, x, tx, W, bias, out, rows, Cin, Cout, K, act, false, pmN, ex)) return rc;
+  if (map_here && io.map_done) *io.map_done = true;
   if (pool && pooled)
     if (int rc = launch_spmm(st, pool, out, pooled, nullptr, nullptr, 1.f, 0.f, B, Cout, true)) return rc;
-  return finish(false);
+  return finish(bits_here);
 }
 
 extern "C" size_t mvh_cheb_conv_bwd_ws_bytes(int32_t B, int32_t N, int32_t Cin, int32_t Cout, int32_t K) {

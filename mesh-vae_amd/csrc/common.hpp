@@ -133,6 +133,7 @@ struct DebugCfg {
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
   int no_patch_bf16 = 0;   // 1: bf16 storage keeps the matrix-pipe slab kernels (cheb_l0h.hip) for the 5k level's backward
+  int no_contract_extras = 0;   // 1: the streaming levels' contraction writes no sign bytes / per-vertex map (k_relu_bits and the loss launch do)
   int no_patch_map = 0;    // 1: the final layer's per-vertex map stays in the loss launch / its own launch (not in the last decoder stage's epilogue)
   int no_patch_unpool = 0; // 1: the last decoder stage reads a stored un-pooled input (the stage before writes it) instead of un-pooling in its loads
   int no_enc0_patch = 0;   // 1: the first layer's forward stays on the slab kernel and the backward builds its stack (k_cheb_tstack)
