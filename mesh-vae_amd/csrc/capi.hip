@@ -53,7 +53,7 @@ static const DebugKey kDebugKeys[] = {
     {"l0_lane_bf", &DebugCfg::l0_lane_bf},       {"l0_hold", &DebugCfg::l0_hold},
     {"enc_dense", &DebugCfg::enc_dense},         {"no_patch", &DebugCfg::no_patch},
     {"patch_flush_first", &DebugCfg::patch_flush_first}, {"no_patch_bwd", &DebugCfg::no_patch_bwd},
-    {"no_enc0_patch", &DebugCfg::no_enc0_patch}, {"no_patch_bf16", &DebugCfg::no_patch_bf16}, {"no_patch_unpool", &DebugCfg::no_patch_unpool}, {"no_patch_map", &DebugCfg::no_patch_map}, {"no_contract_extras", &DebugCfg::no_contract_extras},
+    {"no_enc0_patch", &DebugCfg::no_enc0_patch}, {"no_patch_bf16", &DebugCfg::no_patch_bf16}, {"no_patch_unpool", &DebugCfg::no_patch_unpool}, {"no_patch_map", &DebugCfg::no_patch_map}, {"no_contract_extras", &DebugCfg::no_contract_extras}, {"no_big_tstack", &DebugCfg::no_big_tstack},
 };
 
 static int DebugCfg::*find_debug_key(const char* key, size_t len) {

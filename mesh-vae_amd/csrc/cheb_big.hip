@@ -35,6 +35,8 @@ struct BigArgs {
   const float* mask;    // MODE 0, optional: rows like `in`; an input element counts only where mask > 0 (ReLU backward)
   int with_t0;          // MODE 0: the (masked) input itself is stored as plane 0 and T_k as plane k (K planes)
   int half_ids;         // TIMING ONLY (debug switch big_half_ids): 8 id bytes per vertex and order instead of 16
+  const int32_t* sel_inv;   // MODE 0, optional (with_t0, C <= 4, row layout): ONLY the rows a one-hot pooling selects are stored
+  int n_sel;                // (sel_inv[v] = pooled row or -1), in the layout of cheb_tstack.hip: out = stack [B][K][n_sel + 1][4]
   int pm;               // the stack (MODE 0: tx, MODE 1: G) is PAIR-MAJOR: plane k = [B][C/2][N][2] (C even), so that a
                         // workgroup streams 8 contiguous bytes per vertex instead of 8-byte pieces of 64-byte rows --
                         // with row layout the 8 pair-workgroups of a mesh drift apart, every one of them pulls the whole
@@ -108,7 +110,14 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
           x = make_float2(mk.x > 0.f ? x.x : 0.f, mk.y > 0.f ? x.y : 0.f);
         }
         pl[v] = make_float2(s * x.x, s * x.y);
-        if (a.with_t0) big_store2<VEC>(out_m, (unsigned)(v * ostr), has1, x);
+        if (a.sel_inv) {          // compact stack of the selected rows (plane 0 = x)
+          const int pr = a.sel_inv[v];
+          if (pr >= 0) {
+            float* dst = a.out + (((long long)mesh * a.K) * (a.n_sel + 1) + pr) * 4 + c0;
+            dst[0] = x.x;
+            if (has1) dst[1] = x.y;
+          }
+        } else if (a.with_t0) big_store2<VEC>(out_m, (unsigned)(v * ostr), has1, x);
       }
     }
   } else {  // w_{K-1} = s G_{K-1}
@@ -172,7 +181,16 @@ __global__ void __launch_bounds__(kBigThreads) k_cheb_big(BigArgs a) {
         P[j] = nu;
         if (MODE == 0) {   // T_k = u_k / s
           const float is = dg > 0.f ? __builtin_amdgcn_sqrtf(dg) : 1.f;
-          big_store2<VEC>(tk, (unsigned)(v * ostr), has1, make_float2(nu.x * is, nu.y * is));
+          if (a.sel_inv) {
+            const int pr = a.sel_inv[v];
+            if (pr >= 0) {
+              float* dst = a.out + (((long long)mesh * a.K + k) * (a.n_sel + 1) + pr) * 4 + c0;
+              dst[0] = nu.x * is;
+              if (has1) dst[1] = nu.y * is;
+            }
+          } else {
+            big_store2<VEC>(tk, (unsigned)(v * ostr), has1, make_float2(nu.x * is, nu.y * is));
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // (keeps the unrolled loop from hoisting every vertex's loads: 80 registers)
@@ -248,9 +266,13 @@ bool cheb_big_eligible(const mvh_csr_t* lap, int B, int N, int C, int K) {
 
 template <int MODE>
 static int big_launch(hipStream_t st, const mvh_csr_t* lap, const float* in, float* out, int B, int N, int C, int K,
-                      bool pm, const float* mask = nullptr, bool with_t0 = false) {
+                      bool pm, const float* mask = nullptr, bool with_t0 = false, const int32_t* sel_inv = nullptr,
+                      int n_sel = 0) {
   if (pm && (C & 1)) return fail(MVH_ERR_INVALID, "cheb_big: the pair-major stack needs an even channel count");
-  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, mask, with_t0 ? 1 : 0, dbg().big_half_ids, pm ? 1 : 0};
+  if (sel_inv && (MODE != 0 || pm || C > 4 || !with_t0 || n_sel <= 0))
+    return fail(MVH_ERR_INVALID, "cheb_big: the selected-rows stack is a MODE 0, row-layout, <= 4-channel form with T_0");
+  BigArgs a{in, out, lap->ell, lap->rowinfo, B, N, C, K, (long long)B * N * C, mask, with_t0 ? 1 : 0, dbg().big_half_ids,
+            sel_inv, n_sel, pm ? 1 : 0};
   const size_t lds = (size_t)(N + 1) * 8;
   const int grid = ((B + 7) / 8) * 8 * ((C + 1) / 2);
   auto go = [&](auto kern) -> int {
@@ -272,6 +294,16 @@ int try_cheb_big_tx(hipStream_t st, const mvh_csr_t* lap, const float* x, float*
   if (!cheb_big_eligible(lap, B, N, C, K)) return MVH_OK;
   if (int rc = big_launch<0>(st, lap, x, tx, B, N, C, K, pm, mask, with_t0)) return rc;
   *handled = true;
+  return MVH_OK;
+}
+
+// stack [B][K][n_sel + 1][4] <- T_k(L) x, k = 0 .. K-1, at the rows the one-hot pooling `pool` selects (cheb_tstack.hip's
+// layout, for a level too big for its kernel): what k_stack_dw and k_stack_contract read
+int launch_big_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
+                      int N, int Cin, int K) {
+  MVH_REQUIRE(cheb_big_eligible(lap, B, N, Cin, K) && pool && pool->sel_inv && pool->n_cols == N && Cin <= 4,
+              "cheb_big: selected-rows stack on a level it does not take");
+  if (int rc = big_launch<0>(st, lap, x, stack, B, N, Cin, K, false, nullptr, true, pool->sel_inv, pool->n_rows)) return rc;
   return MVH_OK;
 }
 

@@ -1137,6 +1137,16 @@ int mvh::cheb_conv_fwd_impl(hipStream_t stream, const mvh_csr_t* lap, const floa
   if (io.x_map)
     return fail(MVH_ERR_UNSUPPORTED, "cheb_conv_fwd: strided x is read by the LDS-resident kernels only (N=%d %d->%d K=%d)",
                 N, Cin, Cout, K);
+  // the first layer of a streaming level in front of its one-hot pooling, with the caller's stack buffer (the step engine,
+  // ConvIO::stack_out): T_k x is kept at the SELECTED rows only (cheb_big.hip -> the stack of cheb_tstack.hip) and the
+  // layer's output is contracted from it at those rows -- no full [K][B][N][Cin] stack, no [B][N][Cout] output, no pooling pass
+  if (io.stack_out && pool && pooled && io.out_dead && bits_out && act == MVH_ACT_RELU && Cout == 16 && N + 1 > 5120 &&
+      !io.pooled && tstack_eligible(lap, pool, N, Cin, Cout, K)) {
+    if (int rc = launch_big_tstack(st, lap, pool, x, io.stack_out, B, N, Cin, K)) return rc;
+    if (int rc = launch_stack_contract(st, pool, io.stack_out, W, bias, pooled, bits_out, B, N, Cin, K)) return rc;
+    if (io.stack_done) *io.stack_done = true;
+    return MVH_OK;
+  }
   float* tx = tx_saved;
   if (!tx && K > 1) {
     MVH_REQUIRE(ws && ws_bytes >= mvh_cheb_conv_ws_bytes(B, N, Cin, Cout, K), "cheb_conv_fwd: workspace too small");

@@ -157,7 +157,7 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
   // issued before the current tile is consumed); thread t < n_w owns dW entry (k, ci, co) and
   // n_w <= t < n_out owns db[co].  (A barrier-free variant with wave-uniform rows and broadcast loads
   // was 2-3x slower: 6 dependent small loads per row and lane.)
-  __shared__ float sA[kSdwRows][36];  // [row][k*4 + ci], K <= 8 (+4: bank spread, keeps 16-byte alignment)
+  __shared__ float sA[kSdwRows][52];  // [row][k*4 + ci], K <= 12 (+4: bank spread, keeps 16-byte alignment)
   __shared__ float sB[kSdwRows][36];  // [row][co], Cout <= 32
   const int n_w = a.K * a.Cin * a.Cout, n_out = n_w + a.Cout;
   const int t = threadIdx.x, ty = t >> 3, tx = t & 7;
@@ -166,14 +166,16 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
   const int co = t < n_w ? t % a.Cout : t - n_w;
   const int kc = t < n_w ? (t / a.Cout / a.Cin) * 4 + (t / a.Cout) % a.Cin : 0;
   const int CQ4 = a.Cout >> 2;
-  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pa2 = pa;    // (pa2: planes 8 .. 11 of the deeper layers, K > 8)
   auto fetch = [&](int base) {  // this thread's pieces of the tile starting at `base`, into registers
     pa = make_float4(0.f, 0.f, 0.f, 0.f);
     pb = pa;
+    pa2 = pa;
     const int r = base + ty;
     if (r >= r1) return;
     const int b = r / a.n_sel, v = sel_col[r - b * a.n_sel];
     if (tx < a.K) pa = *reinterpret_cast<const float4*>(stack + (((long long)b * a.K + tx) * (a.n_sel + 1) + (r - b * a.n_sel)) * 4);
+    if (tx + 8 < a.K) pa2 = *reinterpret_cast<const float4*>(stack + (((long long)b * a.K + tx + 8) * (a.n_sel + 1) + (r - b * a.n_sel)) * 4);
     if (tx < CQ4) {
       float4 d = load4_any(dout, (long long)r * a.Cout + tx * 4, a.dout_bf16 != 0);
       if (bits) {
@@ -197,6 +199,7 @@ k_stack_dw(const float* __restrict__ stack, const float* __restrict__ dout, cons
   for (int base = r0; base < r1; base += kSdwRows) {
     const int nr = min(kSdwRows, r1 - base);
     if (tx < a.K) *reinterpret_cast<float4*>(&sA[ty][tx * 4]) = pa;
+    if (tx + 8 < a.K) *reinterpret_cast<float4*>(&sA[ty][(tx + 8) * 4]) = pa2;
     if (tx < CQ4) *reinterpret_cast<float4*>(&sB[ty][tx * 4]) = pb;
     __syncthreads();
     fetch(base + kSdwRows);  // in flight while this tile is consumed
@@ -240,10 +243,13 @@ bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin
   const int need = MVH_CSR_NORMALIZED_LAPLACIAN | MVH_CSR_SYMMETRIC;
   if (!lap || !pool || !lap->rowinfo || !lap->ell || (lap->flags & need) != need) return false;
   if (lap->ell_pairs <= 0 || lap->ell_pairs > 8 || (lap->flags & MVH_CSR_ELL_OVERFLOW)) return false;
-  if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0 || pool->n_rows > 3 * 512) return false;
-  if (Cin < 1 || Cin > 4 || Cout < 4 || Cout > 32 || Cout % 4 != 0 || K < 1 || K > 8) return false;
+  if (!pool->sel_inv || !pool->col || pool->n_cols != N || pool->n_rows <= 0) return false;
+  if (Cin < 1 || Cin > 4 || Cout < 4 || Cout > 32 || Cout % 4 != 0 || K < 1 || K > 12) return false;
   if (K * Cin * Cout + Cout > 512) return false;
-  if (N + 1 <= 2048 || N + 1 > 5120) return false;  // only the 160 KB configuration pays: smaller levels keep the LDS dW kernel
+  if (N + 1 > 5120)   // levels of the streaming kernels: cheb_big.hip builds the same stack (launch_tstack dispatches), 16 outputs
+    return !dbg().no_big_tstack && K >= 2 && Cout == 16 && cheb_big_eligible(lap, 1, N, Cin, K);
+  if (K > 8 || pool->n_rows > 3 * 512) return false;
+  if (N + 1 <= 2048) return false;  // only the 160 KB configuration pays: smaller levels keep the LDS dW kernel
   const int pw = lap->ell_pairs > 4 ? 8 : 4;
   if ((size_t)5120 * (16 + pw * 4) > 160 * 1024) return false;
   return true;
@@ -252,6 +258,7 @@ bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin
 // stack [B][K][n_sel][4] <- T_k(L) x at the selected rows
 int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
                   int N, int Cin, int K) {
+  if (N + 1 > 5120) return launch_big_tstack(st, lap, pool, x, stack, B, N, Cin, K);
   TstackDims d{B, N, K, Cin, pool->n_rows};
   const size_t lds = (size_t)5120 * (16 + 4 * 4);
   // 512 threads x 10 vertices; debug switch tstack_tall: 1024 x 5 (61 VGPRs, 4 waves per SIMD) -- MEASURED the same within
@@ -261,6 +268,52 @@ int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, c
   static LdsAttr attr[2];   // (one per kernel)
   if (int rc = attr[wide ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(B), dim3(wide ? 512 : 1024), lds, st, x, lap->rowinfo, lap->ell, pool->col, stack, d);
+  MVH_LAUNCH_CHECK();
+  return MVH_OK;
+}
+
+// ---- the layer's own forward from the stack: pooled[b][r][0..16) = relu(bias + sum_k sum_ci stack[b][k][r][ci] W[k][ci][:])
+// at the selected rows only, in k_cheb_contract's fma order (k outer, input channel inner), + the sign bytes of those rows at
+// their FINE vertex (what k_stack_dw masks with).  One thread per pooled row.
+__global__ void __launch_bounds__(256)
+k_stack_contract(const float* __restrict__ stack, const float* __restrict__ W, const float* __restrict__ bias,
+                 const int* __restrict__ sel_col, float* __restrict__ pooled, uint8_t* __restrict__ bits, int rows,
+                 int n_sel, int N, int K, int Cin) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int b = r / n_sel, pr = r - b * n_sel;
+  float acc[16];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) acc[co] = bias ? bias[co] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float4 t4 = *reinterpret_cast<const float4*>(stack + (((long long)b * K + k) * (n_sel + 1) + pr) * 4);
+    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* w = W + ((long long)k * Cin + ci) * 16;
+#pragma unroll
+      for (int co = 0; co < 16; ++co) acc[co] = fmaf(tv[ci], w[co], acc[co]);
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 16; ++co) acc[co] = fmaxf(acc[co], 0.f);
+  float* o = pooled + (long long)r * 16;
+#pragma unroll
+  for (int co = 0; co < 16; co += 4) *reinterpret_cast<float4*>(o + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+  if (bits) {
+    const long long vb = ((long long)b * N + sel_col[pr]) * 4;
+#pragma unroll
+    for (int co = 0; co < 16; co += 4)
+      bits[vb + co / 4] = (uint8_t)((acc[co] > 0.f ? 1 : 0) | (acc[co + 1] > 0.f ? 2 : 0) | (acc[co + 2] > 0.f ? 4 : 0) |
+                                    (acc[co + 3] > 0.f ? 8 : 0));
+  }
+}
+
+int launch_stack_contract(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* W, const float* bias,
+                          float* pooled, uint8_t* bits, int B, int N, int Cin, int K) {
+  MVH_REQUIRE(stack && W && pooled && ((uintptr_t)pooled & 15) == 0 && ((uintptr_t)stack & 15) == 0, "stack_contract: bad tensor");
+  const int rows = B * pool->n_rows;
+  hipLaunchKernelGGL(k_stack_contract, dim3(cdiv(rows, 256)), dim3(256), 0, st, stack, W, bias, pool->col, pooled, bits, rows,
+                     pool->n_rows, N, K, Cin);
   MVH_LAUNCH_CHECK();
   return MVH_OK;
 }

@@ -133,6 +133,7 @@ struct DebugCfg {
   int no_patch = 0;        // 1: never take the vertex-patch kernels (cheb_patch.hip): the slab kernels and their lanes everywhere
   int no_patch_bwd = 0;    // 1: the backward of such a layer stays on the slab kernels (forward on the patch kernel)
   int no_patch_bf16 = 0;   // 1: bf16 storage keeps the matrix-pipe slab kernels (cheb_l0h.hip) for the 5k level's backward
+  int no_big_tstack = 0;   // 1: the first layer of a streaming level keeps the full T_k stack pipeline (no selected-rows stack)
   int no_contract_extras = 0;   // 1: the streaming levels' contraction writes no sign bytes / per-vertex map (k_relu_bits and the loss launch do)
   int no_patch_map = 0;    // 1: the final layer's per-vertex map stays in the loss launch / its own launch (not in the last decoder stage's epilogue)
   int no_patch_unpool = 0; // 1: the last decoder stage reads a stored un-pooled input (the stage before writes it) instead of un-pooling in its loads
@@ -351,6 +352,10 @@ int try_cheb_dw_lds(hipStream_t st, const mvh_csr_t* lap, const float* x, const 
 size_t tstack_stack_floats(int B, int n_sel, int K);   // (n_sel = rows the pooling selects = pool->n_rows)
 size_t tstack_ws_floats(int B, int n_sel, int K, int Cin, int Cout);
 bool tstack_eligible(const mvh_csr_t* lap, const mvh_csr_t* pool, int N, int Cin, int Cout, int K);
+int launch_big_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
+                      int N, int Cin, int K);     // (cheb_big.hip: the same stack on a level of the streaming kernels)
+int launch_stack_contract(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* W, const float* bias,
+                          float* pooled, uint8_t* bits, int B, int N, int Cin, int K);
 int launch_tstack(hipStream_t st, const mvh_csr_t* lap, const mvh_csr_t* pool, const float* x, float* stack, int B,
                   int N, int Cin, int K);
 int launch_stack_dw(hipStream_t st, const mvh_csr_t* pool, const float* stack, const float* dout, const uint8_t* bits,

@@ -859,14 +859,21 @@ extern "C" int mvh_vae_backward(mvh_stream_t stream, const mvh_vae_desc_t* d, co
     // (At the 5k level the same order was MEASURED and not kept: 576 us per step against 573, and 594 with the dW
     //  launch cut into two 128-workgroup halves -- the weight-gradient lane then finishes last.)
     const bool dx_first = p.Nn[lvl] + 1 > 5120 && !dbg().no_dx_first;
+    // (the first layer's stack: when the forward left it -- the streaming level's selected-rows form always does -- there is
+    //  nothing to launch here; otherwise its launch belongs to the side-lane form below)
+    const bool stack_ready = pf && pf->pending && pf->x == x && (pf->stream == sstream || !pf->stream);
     if (dx_first && cin == 16 && cout == 16 && !bf && !dbg().no_bwd_fused && !dbg().no_dx_tstack && !dbg().no_big &&
-        !(i == n - 1 && use_tstack)) {   // (the first layer's stack launch below belongs to the side-lane form)
+        !(i == n - 1 && use_tstack && !stack_ready)) {
       // ... and for 16 -> 16 channels both gradients come out of ONE pass over the T_k(dpre) stack (k_big_bwd16,
       // cheb_conv.hip): a single call on the main stream, nothing of this stage on the weight-gradient lane
       TRY(cheb_conv_bwd_impl(main, &d->lap[lvl], &d->lap_t[lvl], F(p.decU[i]), P[ix.decW(i)], F(p.decC[i]), F(p.g_decC[i]),
                              nullptr, F(p.g_decU[i]), G[ix.decW(i)], G[ix.decB(i)], B, p.Nn[lvl], cin, cout, d->K[i],
                              MVH_ACT_RELU, sm, p.scratch_bytes, F(p.pk_dec_b[i]), nullptr, nullptr, BITS(p.decBits[i]),
                              nullptr, nullptr, nullptr, 0, nullptr, &d->up_t[lvl], dst, io));
+      if (i == n - 1 && use_tstack) {          // (stack_ready holds: see the condition)
+        ev_tstack = (!pf->stream && pf->fwd == main) ? nullptr : pf->done;
+        pf->pending = false;
+      }
       continue;
     }
     // A level with a vertex-patch plan (cheb_patch.hip; the 5k level's 16 -> 16 stage): dX, its U^T pooling and the dW / db
