@@ -574,6 +574,41 @@ def test_native_step_hires_20k_equals_module_path():
             assert err < 1e-6, (k, err)
 
 
+def test_hires_20k_first_layer_stack_at_the_pooled_rows_only():
+    """configs[3], first layer: k_cheb_big keeps T_k x at the rows the pooling selects (the stack layout of cheb_tstack.hip),
+    k_stack_contract forms the pooled output from it and k_stack_dw the weight gradient -- against the full-stack pipeline
+    (debug switch no_big_tstack): outputs bitwise (the contraction keeps k_cheb_contract's fma order), gradients to
+    fp32 reassociation (1e-6; the first layer's own weight gradient is summed in another order), and the switch matters."""
+    from conftest import CFG_20K
+    from meshvae_hip import debug_switch
+    from meshvae_hip.engine import NativeStep
+    from model import load_topology
+    from models.cheb_VAE import cheb_VAE
+    dev = torch.device("cuda:0")
+    D, U, A, nn_ = load_topology(os.path.join(ROOT, "tests", "golden", "topology_20k.npz"), dev)
+    B = 2
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(B, nn_[0], 3, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.arange(B) % 2, 2).to(dev)
+    eps = torch.randn(B, 16, generator=g).to(dev)
+    res = []
+    for sw in (0, 1):
+        torch.manual_seed(666)
+        net = cheb_VAE(3, dict(CFG_20K, dropout=0.0), D, U, A, nn_, model="optimal_sigma_VAE").to(dev).train()
+        with debug_switch("no_big_tstack", sw):
+            loss, _, recon, _, _ = NativeStep(net, B).forward_backward(x, x.double(), y, eps=eps)
+            torch.cuda.synchronize()
+        res.append((loss.clone(), recon.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+    differs = False
+    for k, ga in res[0][2].items():
+        gb = res[1][2][k]
+        err = float((ga - gb).norm()) / max(float(gb.norm()), 1e-20)
+        assert err < 1e-6, (k, err)
+        differs = differs or not torch.equal(ga, gb)
+    assert differs, "no_big_tstack changed nothing: the selected-rows stack path did not run"
+
+
 def test_module_forward_is_one_fused_autograd_node():
     """cheb_VAE.forward under grad mode runs the native step behind a single autograd node (what main.py's
     `loss.backward()` then triggers): same numbers as the per-module path, gradients ACCUMULATE like any autograd
